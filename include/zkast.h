@@ -1,0 +1,142 @@
+/* zkast.h — C ABI of libzkast.so: MI355X-native (gfx950) sliding-window log-mel + AST two-stage inference.
+ *
+ * This is the drop-in boundary for ONE path of daostler-tum/zenker-audio-detection: what
+ * `forward_probs` (src/test_long_audio_windows_2stage.py:104-113) does per batch —
+ *     fx(batch, sampling_rate=16000, return_tensors="pt")     -> zk_logmel / zk_features_expand
+ *     model(feats).logits                                      -> zk_ast_forward
+ *     torch.softmax(logits, dim=1)                             -> zk_softmax
+ * — and the two-stage cascade around it (:301-340)              -> zk_two_stage.
+ * The reference has no FFI of its own (pure Python); the binding a maintainer adds is the ctypes layer in
+ * zenker-audio-detection_amd/zkast/lib.py.
+ *
+ * Conventions
+ *  - plain C, no torch types.  Every pointer argument documented "host|device" may be either: the library asks the
+ *    HIP runtime (hipPointerGetAttributes) and stages host memory itself.
+ *  - the caller allocates every output; the library returns no owned memory except zk_last_error()'s string.
+ *  - return value 0 = ok, negative = error (ZK_E_*); no exceptions or aborts cross the boundary.
+ *  - a context is bound to one GPU and one HIP stream and is NOT thread-safe; calls are synchronous on return
+ *    unless the context was switched to async mode with zk_set_async(ctx, 1) (then call zk_synchronize()).
+ */
+#ifndef ZKAST_H
+#define ZKAST_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zk_ctx zk_ctx;
+
+enum { ZK_OK = 0, ZK_E_ARG = -1, ZK_E_HIP = -2, ZK_E_STATE = -3, ZK_E_SHAPE = -4, ZK_E_NOMEM = -5 };
+
+/* compute modes of the transformer GEMMs (all accumulate in fp32; LayerNorm/softmax/residual stream are fp32) */
+enum {
+  ZK_F16 = 1,   /* one fp16 MFMA pass.  Fastest; ~3e-3 max-abs logit error on the synthetic weight sets.        */
+  ZK_F16X3 = 3  /* (hi,lo) fp16 operand pairs, 3 MFMA passes: fp32-equivalent products; meets the 1e-3 tolerance */
+};
+
+/* tensor dtypes accepted by zk_model_load */
+enum { ZK_DT_F32 = 0, ZK_DT_F16 = 1, ZK_DT_BF16 = 2 };
+
+typedef struct {
+  const char* name;    /* state-dict key, transformers 4.x or 5.x scheme                                          */
+  const void* data;    /* HOST pointer, C-contiguous; the library copies, the caller keeps ownership             */
+  int32_t ndim;
+  int64_t shape[4];
+  int32_t dtype;       /* ZK_DT_*                                                                                 */
+} zk_tensor_desc;
+
+/* mirrors config.json of the model directory (ASTConfig, $TF/.../configuration_audio_spectrogram_transformer.py:50-64) */
+typedef struct {
+  int32_t hidden_size, num_hidden_layers, num_attention_heads, intermediate_size;
+  int32_t patch_size, frequency_stride, time_stride, max_length, num_mel_bins, num_labels;
+  float layer_norm_eps;
+} zk_ast_config;
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+/* replaces the module-level DEVICE of the reference (src/test_long_audio_windows_2stage.py:48) */
+int zk_create(int device_id, zk_ctx** out);
+void zk_destroy(zk_ctx* ctx);
+const char* zk_last_error(zk_ctx* ctx);           /* ctx may be NULL: last error of zk_create                     */
+int zk_set_stream(zk_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = the context's own stream                  */
+int zk_set_async(zk_ctx* ctx, int enable);
+int zk_synchronize(zk_ctx* ctx);
+int zk_set_micro_batch(zk_ctx* ctx, int32_t windows); /* forward is chunked into micro-batches (default 64)         */
+const char* zk_version(void);
+
+/* ---- model -------------------------------------------------------------------------------------------------- */
+/* replaces load_stage_model (src/test_long_audio_windows_2stage.py:86-98): weights of stage 0 (Idle/Swallow) or
+ * stage 1 (Healthy/Zenker) plus that stage's extractor statistics (preprocessor_config.json: mean, std).          */
+int zk_model_load(zk_ctx* ctx, int stage, const zk_tensor_desc* tensors, int32_t n_tensors, const zk_ast_config* cfg,
+                  float fx_mean, float fx_std, int32_t compute_mode);
+int zk_model_set_compute_mode(zk_ctx* ctx, int stage, int32_t compute_mode);
+/* the extractor statistics used when a forward runs from the feature slot (fx.mean / fx.std of that stage) */
+int zk_model_set_fx(zk_ctx* ctx, int stage, float fx_mean, float fx_std);
+
+/* ---- feature extraction ------------------------------------------------------------------------------------- */
+/* replaces window_audio (:62-75) + ASTFeatureExtractor._extract_fbank_features.  Windows are
+ * audio[first_start + i*hop : ... + win], i < n_windows; samples past n_samples read as 0.  The un-normalised
+ * log-mel rows stay on the device in the context (the "feature slot"); n_frames = 1 + (win-400)/160, capped at 1024. */
+int zk_logmel(zk_ctx* ctx, const float* audio /*host|device*/, int64_t n_samples, int64_t first_start, int64_t hop,
+              int32_t win, int32_t n_windows);
+/* replaces ASTFeatureExtractor.__call__(...)["input_values"]: zero-pad the slot to 1024 rows and apply
+ * (x - mean) / (2*std) when do_normalize != 0.  out: (n_windows, 1024, 128) fp32, host|device.                     */
+int zk_features_expand(zk_ctx* ctx, float mean, float std, int32_t do_normalize, float* out /*host|device*/);
+/* copy the compact slot out: (n_windows, n_frames, 128) fp32 */
+int zk_features_get(zk_ctx* ctx, float* out /*host|device*/, int32_t* n_windows, int32_t* n_frames);
+
+/* ---- transformer -------------------------------------------------------------------------------------------- */
+/* replaces ASTForAudioClassification.forward: input_values (B,1024,128) fp32 host|device -> logits (B,labels).
+ * input_values == NULL: run on the feature slot (normalised with the stage's mean/std); win_idx (host|device,
+ * may be NULL) then selects/gathers B windows of the slot.                                                        */
+int zk_ast_forward(zk_ctx* ctx, int stage, const float* input_values, const int32_t* win_idx, int32_t B,
+                   float* logits /*host|device*/);
+/* torch.softmax(logits, dim=1) */
+int zk_softmax(zk_ctx* ctx, const float* logits /*host|device*/, int32_t n, int32_t num_labels,
+               float* probs /*host|device*/);
+
+/* ---- cascade ------------------------------------------------------------------------------------------------ */
+/* replaces main():301-340 for one recording: log-mel -> stage-1 -> gate -> stage-2 on the gated windows.
+ * Gate: argmax == 1 and p_swallow >= thr1 (and p_swallow >= fwd_min_prob when fwd_min_prob >= 0,
+ * ..._cache.py:471-478).  Outputs (host|device, caller-sized): s1_logits (N,2), swallow_idx (N), n_swallow (1),
+ * s2_logits (N,2) of which the first *n_swallow rows are valid.                                                   */
+int zk_two_stage(zk_ctx* ctx, const float* audio, int64_t n_samples, int64_t first_start, int64_t hop, int32_t win,
+                 int32_t n_windows, float thr1, float fwd_min_prob, float* s1_logits, int32_t* swallow_idx,
+                 int32_t* n_swallow, float* s2_logits);
+/* the gate alone, on device: logits (N,2) -> probs (N,2, may be NULL), ascending indices, count */
+int zk_gate(zk_ctx* ctx, const float* logits, int32_t n, float thr1, float fwd_min_prob, float* probs,
+            int32_t* swallow_idx, int32_t* n_swallow);
+
+/* ---- load_audio (next row) ---------------------------------------------------------------------- */
+/* torchaudio.functional.resample(wav, orig, new) defaults (sinc_interp_hann, width 6, rolloff 0.99);
+ * out has ceil(new*n_in/orig) samples.  PARITY UNPINNED (torchaudio source absent).                               */
+int zk_resample(zk_ctx* ctx, const float* in /*host|device*/, int64_t n_in, int32_t orig_sr, int32_t new_sr,
+                float* out /*host|device*/, int64_t n_out);
+
+/* ---- introspection / measurement ---------------------------------------------------------------------------- */
+/* per-kernel-class HIP-event timing over the calls made since zk_prof_begin (on the context's stream).
+ * zk_prof_get: name in {"gemm_qkv","gemm_o","gemm_fc1","gemm_fc2","gemm_patch","attention","layernorm","logmel",
+ * "embed","head"} -> accumulated milliseconds and launch count.                                                   */
+int zk_prof_begin(zk_ctx* ctx);
+int zk_prof_end(zk_ctx* ctx);
+int zk_prof_get(zk_ctx* ctx, const char* name, double* ms, int64_t* launches);
+/* debug tap used by the parity tests: keep the fp32 residual stream of the FIRST micro-batch after encoder layer
+ * `layer` (-1 = embeddings output, -2 = off) of the next forward; get copies (n_windows, 1214, 768) to host.        */
+int zk_debug_set_tap(zk_ctx* ctx, int32_t layer);
+int zk_debug_get_tap(zk_ctx* ctx, float* out /*host*/, int32_t n_windows);
+
+/* ---- test hooks: run ONE kernel on caller-provided fp32 HOST data (tests/test_kernels_gpu.py) ------------------ */
+/* LayerNorm(768): x (rows,768) -> out (rows,768) = hi (+ lo when nsplit == 3) of the fp16 output planes            */
+int zk_test_layernorm(zk_ctx* ctx, const float* x, const float* gamma, const float* beta, int32_t rows, float eps,
+                      int32_t nsplit, float* out);
+/* out = x[M,K] . w[N,K]^T + bias with epilogue epi (0 store, 1 gelu, 2 residual += (out is in/out), 3 patch-embed:
+ * M % 1212 == 0, N == 768, pos (1214,768), out ((M/1212)*1214, 768) in/out); N % 256 == 0, K % 64 == 0          */
+int zk_test_gemm(zk_ctx* ctx, const float* x, const float* w, const float* bias, int32_t M, int32_t N, int32_t K,
+                 int32_t epi, int32_t nsplit, const float* pos, float* out);
+/* qkv (W*1214, 2304) -> out (W*1214, 768): softmax(q k^T / 8) v per head                                            */
+int zk_test_attention(zk_ctx* ctx, const float* qkv, int32_t W, int32_t nsplit, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

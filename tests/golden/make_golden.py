@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory.  RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference and
+the `transformers` package); the fixtures it writes are data (inputs + expected outputs) and are committed, this
+script never runs on the GPU box.
+
+Sources of truth:
+  * `transformers.ASTFeatureExtractor` / `ASTForAudioClassification` constructed locally (no hub access) — the
+    third-party code the reference calls (src/test_long_audio_windows_2stage.py:40,89-94,108-110);
+  * the reference module's own pure functions `window_audio`, `forward_probs`, `summarize_stage_outputs`
+    (src/test_long_audio_windows_2stage.py:62-75,104-113,148-195 and ..._cache.py:243-297), imported from
+    /root/reference with an empty `torchaudio` stub (torchaudio is not installed; only load_audio/discover use it).
+
+Weights come from zkast.synth (splitmix64), so only outputs are stored.
+
+    python tests/golden/make_golden.py
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "zenker-audio-detection_amd"))
+
+from transformers import ASTConfig, ASTFeatureExtractor, ASTForAudioClassification  # noqa: E402
+
+from zkast import synth  # noqa: E402
+
+REF = "/root/reference/src"
+S1_MEAN, S1_STD = -1.1509622, 3.5340312      # src/train_ast_stage1_cross_validation.py:104-105
+S2_MEAN, S2_STD = -6.5, 2.75                 # a per-fold style override (train_ast_stage2…:512-514)
+TOKENS = [0, 1, 2, 102, 103, 1213]
+
+
+def load_ref(name):
+    if "torchaudio" not in sys.modules:
+        sys.modules["torchaudio"] = types.ModuleType("torchaudio")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def hf_model(seed, weight_set):
+    m = ASTForAudioClassification(ASTConfig(num_labels=2)).eval()
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_ast_weights(seed, weight_set).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return m
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    ref = load_ref("test_long_audio_windows_2stage")
+    refc = load_ref("test_long_audio_windows_2stage_cache")
+
+    # ---------------- F1: window indexing ----------------
+    f1 = {}
+    for T in [5000, 16000, 16001, 23999, 24000, 40000, 28_800_000]:
+        audio = np.zeros(T, dtype=np.float32)
+        audio[: min(T, 100)] = 1.0
+        wins = ref.window_audio(audio, 1.0, 0.5)
+        f1[str(T)] = {"n": len(wins), "lens": sorted({int(len(w)) for w in wins}),
+                      "first_sum": float(wins[0].sum()), "last_sum": float(wins[-1].sum())}
+    f1["hop_gt_win"] = {"n": len(ref.window_audio(np.zeros(80000, np.float32), 1.0, 1.5))}
+    f1["win_0p25_hop_0p1"] = {"n": len(ref.window_audio(np.zeros(16000, np.float32), 0.25, 0.1))}
+    json.dump(f1, open(os.path.join(HERE, "windows.json"), "w"), indent=1)
+
+    # ---------------- F2: log-mel ----------------
+    wins = synth.golden_windows()
+    fx = ASTFeatureExtractor(mean=S1_MEAN, std=S1_STD)
+    fx_raw = ASTFeatureExtractor(mean=S1_MEAN, std=S1_STD, do_normalize=False)
+    raw = fx_raw(list(wins), sampling_rate=16000, return_tensors="np")["input_values"]
+    nrm = fx(list(wins), sampling_rate=16000, return_tensors="np")["input_values"]
+    assert raw.shape == (6, 1024, 128) and raw.dtype == np.float32
+    assert np.all(raw[:, 98:] == 0.0)
+    # short input (fewer than 98 frames) and long input (2 s -> 198 frames): pad/frames logic
+    short = fx_raw(wins[0][:4000], sampling_rate=16000, return_tensors="np")["input_values"][0]
+    long2 = fx_raw(np.concatenate([wins[0], wins[2]]), sampling_rate=16000, return_tensors="np")["input_values"][0]
+    np.savez_compressed(
+        os.path.join(HERE, "fbank.npz"),
+        raw_rows=raw[:, :98].copy(), norm_rows=nrm[:, :98].copy(), norm_pad_value=nrm[0, 500, 0],
+        mel_filters=fx.mel_filters.astype(np.float64), window=fx.window.astype(np.float64),
+        short_rows=short[:30].copy(), short_n=int((np.abs(short).sum(1) != 0).sum()),
+        long_rows=long2[:198:9].copy(), long_n=int((np.abs(long2).sum(1) != 0).sum()),
+        mean=S1_MEAN, std=S1_STD,
+    )
+    try:
+        fx(list(wins[:1]), sampling_rate=8000)
+        raise SystemExit("expected ValueError")
+    except ValueError as e:
+        sr_err = str(e)[:60]
+
+    # ---------------- F3: model ----------------
+    feats4 = nrm[[0, 1, 2, 4]]
+    f3 = {"input_windows": np.array([0, 1, 2, 4])}
+    for tag, seed, wset in [("wide", 11, "wide"), ("init", 12, "init")]:
+        m = hf_model(seed, wset)
+        out = m(torch.from_numpy(feats4), output_hidden_states=True)
+        hs = out.hidden_states           # embeddings output + each layer output (13)
+        assert len(hs) == 13 and hs[0].shape == (4, 1214, 768)
+        base = m.audio_spectrogram_transformer
+        seq = base.layernorm(hs[-1])
+        pooled = (seq[:, 0] + seq[:, 1]) / 2
+        f3[f"{tag}_logits"] = out.logits.numpy()
+        f3[f"{tag}_pooled"] = pooled.numpy()
+        for nm, t in [("emb", hs[0]), ("layer0", hs[1]), ("layer5", hs[6]), ("layer11", hs[12]), ("final_ln", seq)]:
+            f3[f"{tag}_{nm}_tok"] = t[:, TOKENS].numpy()
+            f3[f"{tag}_{nm}_norm"] = t.norm(dim=-1).numpy()
+        print(tag, "logits", out.logits.numpy().tolist())
+    f3["tokens"] = np.array(TOKENS)
+    np.savez_compressed(os.path.join(HERE, "model.npz"), **f3)
+
+    # ---------------- F4: cascade ----------------
+    w16 = synth.synth_windows(seed=3, n_windows=16)
+    m1 = hf_model(21, "wide")
+    m2 = hf_model(22, "wide")
+    fx1 = ASTFeatureExtractor(mean=S1_MEAN, std=S1_STD)
+    fx2 = ASTFeatureExtractor(mean=S2_MEAN, std=S2_STD)
+    ref.DEVICE = torch.device("cpu")
+    # random weights give near-constant decisions; centre each head on the median logit gap so that the gate
+    # splits the 16 windows.  The shift is stored and re-applied to the synth weights by the tests.
+    shifts = []
+    for m, fxs in ((m1, fx1), (m2, fx2)):
+        lg = m(fxs(list(w16), sampling_rate=16000, return_tensors="pt")["input_values"]).logits.numpy()
+        sh = float(np.median(lg[:, 0] - lg[:, 1]))
+        m.classifier.dense.bias.data[1] += sh
+        shifts.append(sh)
+    p1 = ref.forward_probs(m1, fx1, list(w16), 5)       # ragged batches 5,5,5,1
+    p2 = ref.forward_probs(m2, fx2, list(w16), 16)
+    empty = ref.forward_probs(m1, fx1, [], 5)
+    assert p1.shape == (16, 2) and p1.dtype == np.float32 and empty.shape == (0,)
+    np.savez_compressed(os.path.join(HERE, "cascade.npz"), s1_probs=p1, s2_probs_all=p2,
+                        s1_mean=S1_MEAN, s1_std=S1_STD, s2_mean=S2_MEAN, s2_std=S2_STD,
+                        s1_bias_shift=shifts[0], s2_bias_shift=shifts[1], s1_seed=21, s2_seed=22, audio_seed=3)
+    print("s1 probs[:,1]", p1[:, 1].round(4).tolist())
+
+    # summaries on hand-made tables (incl. argmax-vs-threshold quirk, empty, all-swallow)
+    rng = np.random.default_rng(5)
+    cases = {}
+
+    def run_case(name, s1, thr1, thr2, s2_all, min_prob=None, use_argmax=False):
+        s1 = np.asarray(s1, dtype=np.float32)
+        s2_all = np.asarray(s2_all, dtype=np.float32)
+        pred = s1.argmax(axis=1)
+        pred = np.where((pred == 1) & (s1[:, 1] >= thr1), 1, 0)
+        idx = np.where(pred == 1)[0]
+        if min_prob is not None:
+            idx = idx[s1[idx, 1] >= min_prob]
+        res = [(int(i), s2_all[i]) for i in idx]
+        if use_argmax or min_prob is not None:
+            summ = refc.summarize_stage_outputs(s1, res, ["Idle", "Swallow"], ["Healthy", "Zenker"], thr2, use_argmax)
+        else:
+            summ = ref.summarize_stage_outputs(s1, res, ["Idle", "Swallow"], ["Healthy", "Zenker"], thr2)
+        cases[name] = {"s1": s1.tolist(), "s2_all": s2_all.tolist(), "thr1": thr1, "thr2": thr2,
+                       "min_prob": min_prob, "use_argmax": use_argmax, "swallow_idx": idx.tolist(), "summary": summ}
+
+    def rand_probs(n):
+        a = rng.uniform(0.02, 0.98, n)
+        return np.stack([1 - a, a], 1)
+
+    s1 = rand_probs(12)
+    s2 = rand_probs(12)
+    run_case("thr_0p5", s1, 0.5, 0.5, s2)
+    run_case("thr_0p55_quirk", [[0.48, 0.52], [0.3, 0.7], [0.9, 0.1], [0.46, 0.54]], 0.55, 0.5,
+             [[0.1, 0.9], [0.2, 0.8], [0.5, 0.5], [0.6, 0.4]])
+    run_case("thr_0p9", s1, 0.9, 0.35, s2)
+    run_case("no_swallow", [[0.9, 0.1], [0.8, 0.2], [0.5, 0.5]], 0.5, 0.5, [[0.5, 0.5]] * 3)   # tie -> idle
+    run_case("all_swallow", [[0.1, 0.9], [0.2, 0.8]], 0.5, 0.5, [[0.7, 0.3], [0.5, 0.5]])     # p==thr2 -> zenker
+    run_case("argmax_none_evaluated", [[0.4, 0.6], [0.45, 0.55]], 0.7, 0.5, [[0.5, 0.5]] * 2)
+    run_case("cache_argmax", s1, 0.5, 0.8, s2, use_argmax=True)
+    run_case("cache_min_prob", s1, 0.5, 0.5, s2, min_prob=0.75)
+    meta = {"sampling_rate_error_prefix": sr_err, "cases": cases,
+            "transformers": __import__("transformers").__version__, "torch": torch.__version__,
+            "numpy": np.__version__}
+    json.dump(meta, open(os.path.join(HERE, "cascade_cases.json"), "w"), indent=1, default=lambda o: float(o))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+// Patch-embedding front end: im2col of the (time=1024, mel=128) spectrogram into the A operand of the
+// [B*1212, 256] x [256, 768] patch GEMM, and the cls / distillation rows.
+// Replaces ASTPatchEmbeddings / ASTEmbeddings ($TF/.../modeling_audio_spectrogram_transformer.py:57-61,89-99):
+//   Conv2d(1, 768, 16x16, stride (10,10)) over x[b, 0, freq, time]; token = f*101 + t; K index = kf*16 + kt.
+//
+// Two sources:
+//  * compact: un-normalised log-mel rows [N, n_frames, 128] written by logmel.hip; rows >= n_frames are the
+//    extractor's 0.0 padding; (x - mean) / (2 std) is applied here in fp32 exactly as ASTFeatureExtractor.normalize
+//    ($TF/.../feature_extraction_audio_spectrogram_transformer.py:157-158,228-229).  A window index list lets
+//    stage 2 gather the gated windows without copying features.
+//  * full: caller-provided, already normalised input_values (B, 1024, 128) — the HF model contract.
+#include "zk_common.h"
+
+namespace {
+
+// one thread = 8 consecutive K elements (fixed kf, kt0 = 0 or 8) of one patch row
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ src, int n_frames,
+                                                     const int32_t* __restrict__ win_idx, int n_windows, float mean,
+                                                     float std2, half_t* __restrict__ o_hi, half_t* __restrict__ o_lo) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)n_windows * ZK_NPATCH * 32;
+  if (gid >= total) return;
+  const int seg = (int)(gid & 31);            // 32 segments of 8 per 256-wide row
+  const int64_t prow = gid >> 5;              // b*1212 + f*101 + t
+  const int b = (int)(prow / ZK_NPATCH);
+  const int p = (int)(prow - (int64_t)b * ZK_NPATCH);
+  const int f = p / ZK_TOUT, t = p - f * ZK_TOUT;
+  const int kf = seg >> 1, kt0 = (seg & 1) * 8;
+  const int mel = f * ZK_FSTRIDE + kf;
+  const int time0 = t * ZK_TSTRIDE + kt0;
+  const int w = COMPACT ? (win_idx ? win_idx[b] : b) : b;
+  h8_t hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int time = time0 + j;
+    float v;
+    if constexpr (COMPACT) {
+      const float raw = time < n_frames ? src[((size_t)w * n_frames + time) * ZK_NMEL + mel] : 0.0f;
+      v = (raw - mean) / std2;
+    } else {
+      v = src[((size_t)w * ZK_MAXLEN + time) * ZK_NMEL + mel];
+    }
+    hi[j] = (half_t)v;
+    lo[j] = (half_t)(v - (float)hi[j]);
+  }
+  *(h8_t*)(o_hi + prow * ZK_PATCH_K + seg * 8) = hi;
+  if (o_lo) *(h8_t*)(o_lo + prow * ZK_PATCH_K + seg * 8) = lo;
+}
+
+__global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ hidden, const float* __restrict__ cls,
+                                                       const float* __restrict__ dist,
+                                                       const float* __restrict__ pos, int n_windows) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n_windows * 2 * ZK_HIDDEN) return;
+  const int c = gid % ZK_HIDDEN;
+  const int r = (gid / ZK_HIDDEN) & 1;
+  const int b = gid / (2 * ZK_HIDDEN);
+  hidden[((size_t)b * ZK_SEQ + r) * ZK_HIDDEN + c] = (r == 0 ? cls[c] : dist[c]) + pos[r * ZK_HIDDEN + c];
+}
+
+}  // namespace
+
+void zk_launch_im2col_compact(const float* feats, int n_frames, const int32_t* win_idx, int n_windows, float mean,
+                              float std2, zk_planes out, hipStream_t s) {
+  if (n_windows <= 0) return;
+  const int64_t total = (int64_t)n_windows * ZK_NPATCH * 32;
+  hipLaunchKernelGGL(im2col_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feats, n_frames,
+                     win_idx, n_windows, mean, std2, out.hi, out.lo);
+}
+
+void zk_launch_im2col_full(const float* input_values, int n_windows, zk_planes out, hipStream_t s) {
+  if (n_windows <= 0) return;
+  const int64_t total = (int64_t)n_windows * ZK_NPATCH * 32;
+  hipLaunchKernelGGL(im2col_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, input_values,
+                     ZK_MAXLEN, (const int32_t*)nullptr, n_windows, 0.f, 1.f, out.hi, out.lo);
+}
+
+void zk_launch_cls_rows(float* hidden, const float* cls, const float* dist, const float* pos, int n_windows,
+                        hipStream_t s) {
+  if (n_windows <= 0) return;
+  const int total = n_windows * 2 * ZK_HIDDEN;
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, s, hidden, cls, dist, pos, n_windows);
+}

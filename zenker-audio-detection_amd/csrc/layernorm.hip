@@ -1,0 +1,64 @@
+// LayerNorm(768, eps) over fp32 rows -> fp16 (hi[,lo]) planes for the next MFMA GEMM.
+// Replaces nn.LayerNorm in ASTLayer ($TF/.../modeling_audio_spectrogram_transformer.py:199-200,216,222).
+// One wave per row: 12 floats per lane (3 x dwordx4), two-pass statistics in registers, wave-shuffle reductions.
+// HBM-bound: 3072 B read + 1536 (3072 with the lo plane) B written per row.
+#include "zk_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t row_stride,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int rows, half_t* o_hi,
+                                                        half_t* o_lo, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * row_stride;
+  f4_t v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = *(const f4_t*)(xr + i * 256 + lane * 4);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum(s) * (1.0f / ZK_HIDDEN);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = v[i][j] - mean;
+      q = fmaf(d, d, q);
+    }
+  const float var = wave_sum(q) * (1.0f / ZK_HIDDEN);
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const f4_t g = *(const f4_t*)(gamma + c);
+    const f4_t b = *(const f4_t*)(beta + c);
+    h4_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float y = fmaf((v[i][j] - mean) * rstd, g[j], b[j]);
+      hi[j] = (half_t)y;
+      lo[j] = (half_t)(y - (float)hi[j]);
+    }
+    *(h4_t*)(o_hi + (size_t)row * ZK_HIDDEN + c) = hi;
+    if (o_lo) *(h4_t*)(o_lo + (size_t)row * ZK_HIDDEN + c) = lo;
+  }
+}
+
+}  // namespace
+
+void zk_launch_layernorm(const float* x, int64_t row_stride, const float* gamma, const float* beta, int rows,
+                         zk_planes out, float eps, hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, gamma, beta, rows,
+                     out.hi, out.lo, eps);
+}

@@ -1,0 +1,65 @@
+// Small HBM-bound helpers: fp32 -> (hi, lo) fp16 plane split (weights at load time, test hooks) and the
+// polyphase sinc resampler of load_audio (src/test_long_audio_windows_2stage.py:57-58).
+#include "zk_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, int64_t n, float scale,
+                                                    half_t* __restrict__ hi, half_t* __restrict__ lo) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n) {
+    const f4_t v = *(const f4_t*)(src + i);
+    h4_t h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = v[j] * scale;
+      h[j] = (half_t)x;
+      l[j] = (half_t)(x - (float)h[j]);
+    }
+    *(h4_t*)(hi + i) = h;
+    if (lo) *(h4_t*)(lo + i) = l;
+  } else {
+    for (int64_t k = i; k < n; ++k) {
+      const float x = src[k] * scale;
+      const half_t h = (half_t)x;
+      hi[k] = h;
+      if (lo) lo[k] = (half_t)(x - (float)h);
+    }
+  }
+}
+
+// out[i*neu + p] = sum_j kernels[p][j] * padded[i*orig + j],  padded = zeros(width) ++ in ++ zeros(width+orig)
+// (torchaudio.functional._apply_sinc_resample_kernel: conv1d with stride=orig over the padded waveform).
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, int64_t n_in, int orig, int neu,
+                                                       int width, const float* __restrict__ kernels, int klen,
+                                                       float* __restrict__ out, int64_t n_out) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_out) return;
+  const int64_t i = o / neu;
+  const int p = (int)(o - i * neu);
+  const float* kr = kernels + (size_t)p * klen;
+  const int64_t base = i * orig - width;
+  float acc = 0.f;
+  for (int j = 0; j < klen; ++j) {
+    const int64_t s = base + j;
+    const float x = (s >= 0 && s < n_in) ? in[s] : 0.f;
+    acc = fmaf(kr[j], x, acc);
+  }
+  out[o] = acc;
+}
+
+}  // namespace
+
+void zk_launch_split_f32(const float* src, int64_t n, float scale, half_t* hi, half_t* lo, hipStream_t s) {
+  if (n <= 0) return;
+  const int64_t thr = (n + 3) / 4;
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, s, src, n, scale, hi, lo);
+}
+
+void zk_launch_resample(const float* in, int64_t n_in, int orig, int neu, int width, const float* kernels, int klen,
+                        float* out, int64_t n_out, hipStream_t s) {
+  if (n_out <= 0) return;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, in, n_in, orig, neu,
+                     width, kernels, klen, out, n_out);
+}

@@ -1,0 +1,894 @@
+// libzkast.so — context, model store, forward orchestration and the C ABI declared in include/zkast.h.
+// Host code only (the kernels live in gemm/attention/layernorm/embed/head/logmel/misc .hip).
+#include "../../include/zkast.h"
+#include "zk_common.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    // round up so that slowly growing requests do not re-allocate every call
+    size_t want = bytes + (bytes >> 3) + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+struct PlaneBuf {
+  DevBuf hi, lo;
+  zk_planes get(bool split) const { return zk_planes{hi.as<half_t>(), split ? lo.as<half_t>() : nullptr}; }
+};
+
+struct LayerW {
+  float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bo, *b1, *b2;
+  half_t *wqkv_hi, *wqkv_lo, *wo_hi, *wo_lo, *w1_hi, *w1_lo, *w2_hi, *w2_lo;
+};
+
+struct StageModel {
+  bool loaded = false;
+  int mode = ZK_F16X3;
+  int num_labels = 2;
+  int n_layers = ZK_LAYERS;
+  float eps = 1e-12f;
+  float mean = 0.f, std = 1.f;
+  std::vector<void*> allocs;
+  float *cls = nullptr, *dist = nullptr, *pos = nullptr, *patch_b = nullptr;
+  half_t *patch_w_hi = nullptr, *patch_w_lo = nullptr;
+  LayerW L[ZK_LAYERS];
+  float *lnf_g = nullptr, *lnf_b = nullptr, *lnh_g = nullptr, *lnh_b = nullptr, *head_w = nullptr, *head_b = nullptr;
+  void release() {
+    for (void* p : allocs) (void)hipFree(p);
+    allocs.clear();
+    loaded = false;
+  }
+};
+
+enum ProfClass { P_GEMM_QKV, P_GEMM_O, P_GEMM_FC1, P_GEMM_FC2, P_GEMM_PATCH, P_ATTN, P_LN, P_LOGMEL, P_EMBED, P_HEAD, P_N };
+const char* kProfNames[P_N] = {"gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch",
+                               "attention", "layernorm", "logmel", "embed", "head"};
+
+}  // namespace
+
+struct zk_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  bool async = false;
+  int micro_batch = 64;
+  std::string err;
+  StageModel model[2];
+
+  // feature-extraction tables (fp64) and slot
+  double *d_hann = nullptr, *d_tw = nullptr, *d_mel = nullptr;
+  int32_t *d_mel_lo = nullptr, *d_mel_hi = nullptr;
+  DevBuf feat;  // compact [n_windows, n_frames, 128] fp32
+  int feat_windows = 0, feat_frames = 0;
+
+  // staging + workspace
+  DevBuf st_in, st_out, st_idx, audio_dev, s1_logits, s2_logits, gate_idx, gate_cnt, tmp_f32;
+  DevBuf hidden;
+  PlaneBuf patchA, xn, qkv, att, mid;
+  int ws_windows = 0;
+  bool ws_split = false;
+
+  // resampler kernel cache
+  DevBuf rs_kern;
+  int rs_orig = 0, rs_new = 0, rs_width = 0, rs_klen = 0;
+
+  // profiling
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  std::vector<std::pair<int, int>> ev_used;  // (class, pool index)
+  double prof_ms[P_N] = {0};
+  int64_t prof_n[P_N] = {0};
+
+  // debug tap
+  int tap_layer = -2;
+  DevBuf tap;
+  int tap_windows = 0;
+};
+
+namespace {
+
+int fail(zk_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_err = buf;
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e__ = (expr);                                                                              \
+    if (e__ != hipSuccess) return fail((c), ZK_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                                       __FILE__, __LINE__);                                               \
+  } while (0)
+
+bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof a);
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+struct ProfScope {
+  zk_ctx* c; int cls; int idx = -1;
+  ProfScope(zk_ctx* c_, int cls_) : c(c_), cls(cls_) {
+    if (!c->prof) return;
+    idx = (int)c->ev_used.size();
+    if (idx >= (int)c->ev_pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { idx = -1; return; }
+      c->ev_pool.push_back({a, b});
+    }
+    c->ev_used.push_back({cls, idx});
+    (void)hipEventRecord(c->ev_pool[idx].first, c->stream);
+  }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->ev_pool[idx].second, c->stream); }
+};
+
+// ---- fbank tables: mel_filter_bank(257,128,20,8000,16000,None,"kaldi",True), np.hanning(400), FFT twiddles ----
+void build_tables(std::vector<double>& hann, std::vector<double>& tw, std::vector<double>& mel,
+                  std::vector<int32_t>& lo, std::vector<int32_t>& hi) {
+  const int M = ZK_FRAME_LEN;
+  hann.resize(M);
+  for (int i = 0; i < M; ++i) {
+    const double n = (double)(1 - M + 2 * i);
+    hann[i] = 0.5 + 0.5 * cos(M_PI * n / (double)(M - 1));
+  }
+  tw.resize(512);
+  for (int k = 0; k < 256; ++k) {
+    const double a = -2.0 * M_PI * (double)k / 512.0;
+    tw[2 * k] = cos(a);
+    tw[2 * k + 1] = sin(a);
+  }
+  auto h2m = [](double f) { return 1127.0 * log(1.0 + f / 700.0); };
+  const int NF = ZK_NMEL, NB = ZK_NBINS;
+  const double mel_min = h2m(20.0), mel_max = h2m(8000.0);
+  std::vector<double> mf(NF + 2), ff(NB);
+  const double step = (mel_max - mel_min) / (double)(NF + 1);
+  for (int i = 0; i < NF + 2; ++i) mf[i] = (double)i * step + mel_min;
+  mf[NF + 1] = mel_max;
+  const double binw = 16000.0 / ((NB - 1) * 2.0);
+  for (int k = 0; k < NB; ++k) ff[k] = h2m(binw * (double)k);
+  mel.assign((size_t)NB * NF, 0.0);
+  lo.assign(NF, NB);
+  hi.assign(NF, 0);
+  for (int k = 0; k < NB; ++k)
+    for (int m = 0; m < NF; ++m) {
+      const double down = -(mf[m] - ff[k]) / (mf[m + 1] - mf[m]);
+      const double up = (mf[m + 2] - ff[k]) / (mf[m + 2] - mf[m + 1]);
+      double v = down < up ? down : up;
+      if (!(v > 0.0)) v = 0.0;
+      mel[(size_t)k * NF + m] = v;
+      if (v != 0.0) {
+        if (k < lo[m]) lo[m] = k;
+        if (k + 1 > hi[m]) hi[m] = k + 1;
+      }
+    }
+  for (int m = 0; m < NF; ++m)
+    if (hi[m] == 0) lo[m] = 0;  // all-zero filter: empty range
+}
+
+template <class T>
+int upload(zk_ctx* c, const std::vector<T>& v, T** out) {
+  HIPCHK(c, hipMalloc((void**)out, v.size() * sizeof(T)));
+  HIPCHK(c, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return ZK_OK;
+}
+
+int n_frames_for(int win) {
+  if (win < ZK_FRAME_LEN) return 0;
+  int n = 1 + (win - ZK_FRAME_LEN) / ZK_FRAME_HOP;
+  return n > ZK_MAXLEN ? ZK_MAXLEN : n;
+}
+
+// ---- host tensor -> fp32 ----
+float half_bits_to_float(uint16_t h) {
+  const uint32_t s = (h >> 15) & 1, e = (h >> 10) & 0x1F, m = h & 0x3FF;
+  uint32_t out;
+  if (e == 0) {
+    if (m == 0) out = s << 31;
+    else {
+      int ee = -1; uint32_t mm = m;
+      do { ++ee; mm <<= 1; } while (!(mm & 0x400));
+      out = (s << 31) | ((uint32_t)(127 - 15 - ee) << 23) | ((mm & 0x3FF) << 13);
+    }
+  } else if (e == 31) out = (s << 31) | 0x7F800000u | (m << 13);
+  else out = (s << 31) | ((e - 15 + 127) << 23) | (m << 13);
+  float f; memcpy(&f, &out, 4); return f;
+}
+
+bool to_f32(const zk_tensor_desc& t, std::vector<float>& out) {
+  size_t n = 1;
+  for (int i = 0; i < t.ndim; ++i) n *= (size_t)t.shape[i];
+  out.resize(n);
+  if (t.dtype == ZK_DT_F32) memcpy(out.data(), t.data, n * 4);
+  else if (t.dtype == ZK_DT_F16) { const uint16_t* p = (const uint16_t*)t.data; for (size_t i = 0; i < n; ++i) out[i] = half_bits_to_float(p[i]); }
+  else if (t.dtype == ZK_DT_BF16) { const uint16_t* p = (const uint16_t*)t.data; for (size_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)p[i] << 16; memcpy(&out[i], &u, 4); } }
+  else return false;
+  return true;
+}
+
+struct TensorIndex {
+  std::map<std::string, const zk_tensor_desc*> m;
+  const zk_tensor_desc* find(std::initializer_list<std::string> names) const {
+    for (auto& n : names) { auto it = m.find(n); if (it != m.end()) return it->second; }
+    return nullptr;
+  }
+};
+
+size_t numel(const zk_tensor_desc* t) { size_t n = 1; for (int i = 0; i < t->ndim; ++i) n *= (size_t)t->shape[i]; return n; }
+
+int dev_f32(zk_ctx* c, StageModel& sm, const std::vector<float>& v, float** out) {
+  HIPCHK(c, hipMalloc((void**)out, v.size() * 4));
+  sm.allocs.push_back(*out);
+  HIPCHK(c, hipMemcpyAsync(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ZK_OK;
+}
+
+int dev_planes(zk_ctx* c, StageModel& sm, const std::vector<float>& v, half_t** hi, half_t** lo) {
+  HIPCHK(c, c->tmp_f32.ensure(v.size() * 4));
+  HIPCHK(c, hipMemcpyAsync(c->tmp_f32.p, v.data(), v.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMalloc((void**)hi, v.size() * 2)); sm.allocs.push_back(*hi);
+  HIPCHK(c, hipMalloc((void**)lo, v.size() * 2)); sm.allocs.push_back(*lo);
+  zk_launch_split_f32(c->tmp_f32.as<float>(), (int64_t)v.size(), 1.0f, *hi, *lo, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ZK_OK;
+}
+
+int ensure_workspace(zk_ctx* c, int windows, bool split) {
+  if (windows <= c->ws_windows && (!split || c->ws_split)) return ZK_OK;
+  const int w = windows > c->ws_windows ? windows : c->ws_windows;
+  const bool sp = split || c->ws_split;
+  const size_t M = (size_t)w * ZK_SEQ + 256;
+  HIPCHK(c, c->hidden.ensure(M * ZK_HIDDEN * 4));
+  auto pl = [&](PlaneBuf& b, size_t elems) -> hipError_t {
+    hipError_t e = b.hi.ensure(elems * 2);
+    if (e != hipSuccess) return e;
+    return sp ? b.lo.ensure(elems * 2) : hipSuccess;
+  };
+  HIPCHK(c, pl(c->patchA, M * ZK_PATCH_K));
+  HIPCHK(c, pl(c->xn, M * ZK_HIDDEN));
+  HIPCHK(c, pl(c->qkv, M * 3 * ZK_HIDDEN));
+  HIPCHK(c, pl(c->att, M * ZK_HIDDEN));
+  HIPCHK(c, pl(c->mid, M * ZK_INTER));
+  c->ws_windows = w;
+  c->ws_split = sp;
+  return ZK_OK;
+}
+
+void run_gemm(zk_ctx* c, int cls, zk_planes x, const half_t* w_hi, const half_t* w_lo, const float* bias, int M, int N,
+              int K, int epi, int nsplit, zk_planes out, float* resid, const float* pos, int lo_n_limit) {
+  ProfScope ps(c, cls);
+  zk_gemm_args a;
+  a.x_hi = x.hi; a.x_lo = x.lo; a.w_hi = w_hi; a.w_lo = w_lo; a.bias = bias;
+  a.M = M; a.N = N; a.K = K;
+  a.o_hi = out.hi; a.o_lo = (nsplit == 3) ? out.lo : nullptr;
+  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit;
+  zk_launch_gemm(a, epi, nsplit, c->stream);
+}
+
+// forward of nb windows (one micro-batch) whose patch matrix is already in c->patchA
+int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
+  const int ns = sm.mode;
+  const bool sp = ns == 3;
+  const int M = nb * ZK_SEQ;
+  float* hidden = c->hidden.as<float>();
+  zk_planes pa = c->patchA.get(sp), xn = c->xn.get(sp), qkv = c->qkv.get(sp), att = c->att.get(sp), mid = c->mid.get(sp);
+  {
+    ProfScope ps(c, P_EMBED);
+    zk_launch_cls_rows(hidden, sm.cls, sm.dist, sm.pos, nb, c->stream);
+  }
+  run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w_hi, sm.patch_w_lo, sm.patch_b, nb * ZK_NPATCH, ZK_HIDDEN, ZK_PATCH_K,
+           ZK_EPI_PATCH, ns, zk_planes{nullptr, nullptr}, hidden, sm.pos, 0);
+  if (c->tap_layer == -1) {
+    HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
+    HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
+    c->tap_windows = nb;
+  }
+  for (int l = 0; l < sm.n_layers; ++l) {
+    const LayerW& L = sm.L[l];
+    { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, M, xn, sm.eps, c->stream); }
+    run_gemm(c, P_GEMM_QKV, xn, L.wqkv_hi, L.wqkv_lo, L.bqkv, M, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv,
+             nullptr, nullptr, 2 * ZK_HIDDEN);
+    { ProfScope ps(c, P_ATTN); zk_launch_attention(qkv, att, nb, ns, c->stream); }
+    run_gemm(c, P_GEMM_O, att, L.wo_hi, L.wo_lo, L.bo, M, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
+             zk_planes{nullptr, nullptr}, hidden, nullptr, 0);
+    { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln2_g, L.ln2_b, M, xn, sm.eps, c->stream); }
+    run_gemm(c, P_GEMM_FC1, xn, L.w1_hi, L.w1_lo, L.b1, M, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid, nullptr, nullptr,
+             ZK_INTER);
+    run_gemm(c, P_GEMM_FC2, mid, L.w2_hi, L.w2_lo, L.b2, M, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
+             zk_planes{nullptr, nullptr}, hidden, nullptr, 0);
+    if (c->tap_layer == l) {
+      HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
+      HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
+      c->tap_windows = nb;
+    }
+  }
+  {
+    ProfScope ps(c, P_HEAD);
+    zk_launch_head(hidden, nb, sm.lnf_g, sm.lnf_b, sm.lnh_g, sm.lnh_b, sm.head_w, sm.head_b, sm.num_labels, sm.eps,
+                   d_logits, c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
+  return ZK_OK;
+}
+
+// src_full != nullptr: device (B,1024,128) normalised; else feature slot with optional device index list
+int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d_idx, int B, float* d_logits) {
+  StageModel& sm = c->model[stage];
+  const bool sp = sm.mode == 3;
+  const int mbs = c->micro_batch;
+  int rc = ensure_workspace(c, B < mbs ? B : mbs, sp);
+  if (rc) return rc;
+  bool tapped = false;
+  const int saved_tap = c->tap_layer;
+  for (int b0 = 0; b0 < B; b0 += mbs) {
+    const int nb = (B - b0) < mbs ? (B - b0) : mbs;
+    {
+      ProfScope ps(c, P_EMBED);
+      if (src_full)
+        zk_launch_im2col_full(src_full + (size_t)b0 * ZK_MAXLEN * ZK_NMEL, nb, c->patchA.get(sp), c->stream);
+      else
+        zk_launch_im2col_compact(c->feat.as<float>() + (d_idx ? 0 : (size_t)b0 * c->feat_frames * ZK_NMEL),
+                                 c->feat_frames, d_idx ? d_idx + b0 : nullptr, nb, sm.mean, sm.std * 2.0f,
+                                 c->patchA.get(sp), c->stream);
+    }
+    if (tapped) c->tap_layer = -2;  // tap only the first micro-batch
+    rc = forward_micro(c, sm, nb, d_logits + (size_t)b0 * sm.num_labels);
+    tapped = true;
+    if (rc) { c->tap_layer = saved_tap; return rc; }
+  }
+  c->tap_layer = saved_tap;
+  return ZK_OK;
+}
+
+int finish(zk_ctx* c) {
+  if (!c->async) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ZK_OK;
+}
+
+// copy helpers honouring host|device on either side
+int to_device(zk_ctx* c, const void* src, size_t bytes, DevBuf& stage, const void** out) {
+  if (is_device_ptr(src)) { *out = src; return ZK_OK; }
+  HIPCHK(c, stage.ensure(bytes));
+  HIPCHK(c, hipMemcpyAsync(stage.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  *out = stage.p;
+  return ZK_OK;
+}
+
+int from_device(zk_ctx* c, const void* dsrc, void* dst, size_t bytes) {
+  if (bytes == 0) return ZK_OK;
+  const hipMemcpyKind k = is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  HIPCHK(c, hipMemcpyAsync(dst, dsrc, bytes, k, c->stream));
+  if (k == hipMemcpyDeviceToHost) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ZK_OK;
+}
+
+int check_stage(zk_ctx* c, int stage) {
+  if (!c) return ZK_E_ARG;
+  if (stage < 0 || stage > 1) return fail(c, ZK_E_ARG, "stage must be 0 or 1, got %d", stage);
+  if (!c->model[stage].loaded) return fail(c, ZK_E_STATE, "stage %d has no model loaded (zk_model_load)", stage);
+  return ZK_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+const char* zk_version(void) { return "zkast 0.1 (gfx950)"; }
+
+int zk_create(int device_id, zk_ctx** out) {
+  if (!out) return fail(nullptr, ZK_E_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(nullptr, ZK_E_HIP, "no HIP device visible: libzkast needs an MI355X (gfx950) GPU; there is no CPU fallback");
+  }
+  if (device_id < 0 || device_id >= n) return fail(nullptr, ZK_E_ARG, "device_id %d out of range [0,%d)", device_id, n);
+  zk_ctx* c = new zk_ctx();
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess) { delete c; return fail(nullptr, ZK_E_HIP, "hipSetDevice(%d) failed", device_id); }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      std::string a = prop.gcnArchName;
+      delete c;
+      return fail(nullptr, ZK_E_HIP, "device %d is %s; libzkast is built for gfx950 only", device_id, a.c_str());
+    }
+  }
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, ZK_E_HIP, "hipStreamCreate failed"); }
+  c->stream = c->own_stream;
+  std::vector<double> hann, tw, mel;
+  std::vector<int32_t> lo, hi;
+  build_tables(hann, tw, mel, lo, hi);
+  int rc = upload(c, hann, &c->d_hann);
+  if (!rc) rc = upload(c, tw, &c->d_tw);
+  if (!rc) rc = upload(c, mel, &c->d_mel);
+  if (!rc) rc = upload(c, lo, &c->d_mel_lo);
+  if (!rc) rc = upload(c, hi, &c->d_mel_hi);
+  if (rc) { g_create_err = c->err; zk_destroy(c); return rc; }
+  *out = c;
+  return ZK_OK;
+}
+
+void zk_destroy(zk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto& m : c->model) m.release();
+  for (void* p : {(void*)c->d_hann, (void*)c->d_tw, (void*)c->d_mel, (void*)c->d_mel_lo, (void*)c->d_mel_hi})
+    if (p) (void)hipFree(p);
+  for (DevBuf* b : {&c->feat, &c->st_in, &c->st_out, &c->st_idx, &c->audio_dev, &c->s1_logits, &c->s2_logits, &c->gate_idx,
+                    &c->gate_cnt, &c->tmp_f32, &c->hidden, &c->rs_kern, &c->tap})
+    b->release();
+  for (PlaneBuf* b : {&c->patchA, &c->xn, &c->qkv, &c->att, &c->mid}) { b->hi.release(); b->lo.release(); }
+  for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* zk_last_error(zk_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int zk_set_stream(zk_ctx* c, void* s) {
+  if (!c) return ZK_E_ARG;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return ZK_OK;
+}
+int zk_set_async(zk_ctx* c, int e) { if (!c) return ZK_E_ARG; c->async = e != 0; return ZK_OK; }
+int zk_synchronize(zk_ctx* c) { if (!c) return ZK_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return ZK_OK; }
+int zk_set_micro_batch(zk_ctx* c, int32_t w) {
+  if (!c) return ZK_E_ARG;
+  if (w < 1 || w > 4096) return fail(c, ZK_E_ARG, "micro batch %d out of range [1,4096]", w);
+  c->micro_batch = w;
+  return ZK_OK;
+}
+
+int zk_model_load(zk_ctx* c, int stage, const zk_tensor_desc* t, int32_t n, const zk_ast_config* cfg, float fx_mean,
+                  float fx_std, int32_t mode) {
+  if (!c) return ZK_E_ARG;
+  if (stage < 0 || stage > 1) return fail(c, ZK_E_ARG, "stage must be 0 or 1");
+  if (!t || n <= 0 || !cfg) return fail(c, ZK_E_ARG, "tensors/cfg missing");
+  if (mode != ZK_F16 && mode != ZK_F16X3) return fail(c, ZK_E_ARG, "compute_mode must be ZK_F16 (1) or ZK_F16X3 (3)");
+  if (cfg->hidden_size != ZK_HIDDEN || cfg->num_attention_heads != ZK_HEADS || cfg->intermediate_size != ZK_INTER ||
+      cfg->patch_size != ZK_PATCH || cfg->frequency_stride != ZK_FSTRIDE || cfg->time_stride != ZK_TSTRIDE ||
+      cfg->max_length != ZK_MAXLEN || cfg->num_mel_bins != ZK_NMEL)
+    return fail(c, ZK_E_SHAPE, "unsupported ASTConfig: this build is specialised to hidden 768 / 12 heads / mlp 3072 / "
+                               "patch 16 stride 10x10 / 1024x128 input");
+  if (cfg->num_hidden_layers < 1 || cfg->num_hidden_layers > ZK_LAYERS) return fail(c, ZK_E_SHAPE, "num_hidden_layers must be 1..12");
+  if (cfg->num_labels < 1 || cfg->num_labels > 64) return fail(c, ZK_E_SHAPE, "num_labels must be 1..64");
+  if (!(fx_std > 0.f)) return fail(c, ZK_E_ARG, "fx_std must be > 0");
+  HIPCHK(c, hipSetDevice(c->device));
+  StageModel& sm = c->model[stage];
+  sm.release();
+  sm.mode = mode; sm.num_labels = cfg->num_labels; sm.n_layers = cfg->num_hidden_layers; sm.eps = cfg->layer_norm_eps;
+  sm.mean = fx_mean; sm.std = fx_std;
+
+  TensorIndex ix;
+  for (int i = 0; i < n; ++i) if (t[i].name && t[i].data) ix.m[t[i].name] = &t[i];
+  const std::string P = "audio_spectrogram_transformer.";
+  std::vector<float> v, v2;
+  auto need = [&](std::initializer_list<std::string> names, size_t want, std::vector<float>& out) -> int {
+    const zk_tensor_desc* d = ix.find(names);
+    if (!d) return fail(c, ZK_E_SHAPE, "missing tensor '%s'", names.begin()->c_str());
+    if (numel(d) != want) return fail(c, ZK_E_SHAPE, "tensor '%s' has %zu elements, expected %zu", d->name, numel(d), want);
+    if (!to_f32(*d, out)) return fail(c, ZK_E_ARG, "tensor '%s': unsupported dtype %d", d->name, d->dtype);
+    return ZK_OK;
+  };
+  int rc;
+#define NEEDF(dst, want, ...) do { if ((rc = need({__VA_ARGS__}, (want), v))) return rc; if ((rc = dev_f32(c, sm, v, &(dst)))) return rc; } while (0)
+#define NEEDP(hi, lo, want, ...) do { if ((rc = need({__VA_ARGS__}, (want), v))) return rc; if ((rc = dev_planes(c, sm, v, &(hi), &(lo)))) return rc; } while (0)
+  NEEDF(sm.cls, ZK_HIDDEN, P + "embeddings.cls_token");
+  NEEDF(sm.dist, ZK_HIDDEN, P + "embeddings.distillation_token");
+  NEEDF(sm.pos, (size_t)ZK_SEQ * ZK_HIDDEN, P + "embeddings.position_embeddings");
+  NEEDF(sm.patch_b, ZK_HIDDEN, P + "embeddings.patch_embeddings.projection.bias");
+  NEEDP(sm.patch_w_hi, sm.patch_w_lo, (size_t)ZK_HIDDEN * ZK_PATCH_K, P + "embeddings.patch_embeddings.projection.weight");
+  for (int l = 0; l < sm.n_layers; ++l) {
+    LayerW& L = sm.L[l];
+    const std::string a5 = P + "layers." + std::to_string(l) + ".";
+    const std::string a4 = P + "encoder.layer." + std::to_string(l) + ".";
+    // fused QKV weight [2304,768] and bias
+    std::vector<float> wq((size_t)3 * ZK_HIDDEN * ZK_HIDDEN), bq(3 * ZK_HIDDEN);
+    const char* n5[3] = {"attention.q_proj", "attention.k_proj", "attention.v_proj"};
+    const char* n4[3] = {"attention.attention.query", "attention.attention.key", "attention.attention.value"};
+    for (int j = 0; j < 3; ++j) {
+      if ((rc = need({a5 + n5[j] + ".weight", a4 + n4[j] + ".weight"}, (size_t)ZK_HIDDEN * ZK_HIDDEN, v))) return rc;
+      memcpy(wq.data() + (size_t)j * ZK_HIDDEN * ZK_HIDDEN, v.data(), v.size() * 4);
+      if ((rc = need({a5 + n5[j] + ".bias", a4 + n4[j] + ".bias"}, ZK_HIDDEN, v))) return rc;
+      memcpy(bq.data() + (size_t)j * ZK_HIDDEN, v.data(), v.size() * 4);
+    }
+    if ((rc = dev_planes(c, sm, wq, &L.wqkv_hi, &L.wqkv_lo))) return rc;
+    if ((rc = dev_f32(c, sm, bq, &L.bqkv))) return rc;
+    NEEDP(L.wo_hi, L.wo_lo, (size_t)ZK_HIDDEN * ZK_HIDDEN, a5 + "attention.o_proj.weight", a4 + "attention.output.dense.weight");
+    NEEDF(L.bo, ZK_HIDDEN, a5 + "attention.o_proj.bias", a4 + "attention.output.dense.bias");
+    NEEDP(L.w1_hi, L.w1_lo, (size_t)ZK_INTER * ZK_HIDDEN, a5 + "mlp.fc1.weight", a4 + "intermediate.dense.weight");
+    NEEDF(L.b1, ZK_INTER, a5 + "mlp.fc1.bias", a4 + "intermediate.dense.bias");
+    NEEDP(L.w2_hi, L.w2_lo, (size_t)ZK_INTER * ZK_HIDDEN, a5 + "mlp.fc2.weight", a4 + "output.dense.weight");
+    NEEDF(L.b2, ZK_HIDDEN, a5 + "mlp.fc2.bias", a4 + "output.dense.bias");
+    NEEDF(L.ln1_g, ZK_HIDDEN, a5 + "layernorm_before.weight", a4 + "layernorm_before.weight");
+    NEEDF(L.ln1_b, ZK_HIDDEN, a5 + "layernorm_before.bias", a4 + "layernorm_before.bias");
+    NEEDF(L.ln2_g, ZK_HIDDEN, a5 + "layernorm_after.weight", a4 + "layernorm_after.weight");
+    NEEDF(L.ln2_b, ZK_HIDDEN, a5 + "layernorm_after.bias", a4 + "layernorm_after.bias");
+  }
+  NEEDF(sm.lnf_g, ZK_HIDDEN, P + "layernorm.weight");
+  NEEDF(sm.lnf_b, ZK_HIDDEN, P + "layernorm.bias");
+  NEEDF(sm.lnh_g, ZK_HIDDEN, "classifier.layernorm.weight");
+  NEEDF(sm.lnh_b, ZK_HIDDEN, "classifier.layernorm.bias");
+  NEEDF(sm.head_w, (size_t)sm.num_labels * ZK_HIDDEN, "classifier.dense.weight");
+  NEEDF(sm.head_b, (size_t)sm.num_labels, "classifier.dense.bias");
+#undef NEEDF
+#undef NEEDP
+  sm.loaded = true;
+  return ZK_OK;
+}
+
+int zk_model_set_compute_mode(zk_ctx* c, int stage, int32_t mode) {
+  int rc = check_stage(c, stage);
+  if (rc) return rc;
+  if (mode != ZK_F16 && mode != ZK_F16X3) return fail(c, ZK_E_ARG, "compute_mode must be 1 or 3");
+  c->model[stage].mode = mode;
+  return ZK_OK;
+}
+
+int zk_model_set_fx(zk_ctx* c, int stage, float fx_mean, float fx_std) {
+  int rc = check_stage(c, stage);
+  if (rc) return rc;
+  if (!(fx_std > 0.f)) return fail(c, ZK_E_ARG, "fx_std must be > 0");
+  c->model[stage].mean = fx_mean;
+  c->model[stage].std = fx_std;
+  return ZK_OK;
+}
+
+int zk_logmel(zk_ctx* c, const float* audio, int64_t n_samples, int64_t first_start, int64_t hop, int32_t win,
+              int32_t n_windows) {
+  if (!c) return ZK_E_ARG;
+  if (!audio || n_samples <= 0) return fail(c, ZK_E_ARG, "audio is empty");
+  if (n_windows < 0 || hop < 0 || first_start < 0) return fail(c, ZK_E_ARG, "negative window geometry");
+  const int nf = n_frames_for(win);
+  if (nf <= 0) return fail(c, ZK_E_SHAPE, "window of %d samples is shorter than one 400-sample frame", win);
+  HIPCHK(c, hipSetDevice(c->device));
+  const void* d_audio = nullptr;
+  int rc = to_device(c, audio, (size_t)n_samples * 4, c->audio_dev, &d_audio);
+  if (rc) return rc;
+  HIPCHK(c, c->feat.ensure((size_t)(n_windows > 0 ? n_windows : 1) * nf * ZK_NMEL * 4));
+  c->feat_windows = n_windows;
+  c->feat_frames = nf;
+  {
+    ProfScope ps(c, P_LOGMEL);
+    zk_launch_logmel((const float*)d_audio, n_samples, first_start, hop, win, n_windows, nf, c->d_hann, c->d_tw, c->d_mel,
+                     c->d_mel_lo, c->d_mel_hi, c->feat.as<float>(), c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
+int zk_features_expand(zk_ctx* c, float mean, float std, int32_t do_normalize, float* out) {
+  if (!c || !out) return ZK_E_ARG;
+  if (do_normalize && !(std > 0.f)) return fail(c, ZK_E_ARG, "std must be > 0");
+  if (!do_normalize) { mean = 0.f; std = 1.f; }
+  if (c->feat_windows <= 0) return ZK_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)c->feat_windows * ZK_MAXLEN * ZK_NMEL * 4;
+  float* d_out = out;
+  const bool dev = is_device_ptr(out);
+  if (!dev) { HIPCHK(c, c->st_out.ensure(bytes)); d_out = c->st_out.as<float>(); }
+  zk_launch_expand_features(c->feat.as<float>(), c->feat_frames, c->feat_windows, mean, std * 2.0f, do_normalize, d_out,
+                            c->stream);
+  HIPCHK(c, hipGetLastError());
+  if (!dev) return from_device(c, d_out, out, bytes);
+  return finish(c);
+}
+
+int zk_features_get(zk_ctx* c, float* out, int32_t* n_windows, int32_t* n_frames) {
+  if (!c) return ZK_E_ARG;
+  if (n_windows) *n_windows = c->feat_windows;
+  if (n_frames) *n_frames = c->feat_frames;
+  if (out && c->feat_windows > 0)
+    return from_device(c, c->feat.p, out, (size_t)c->feat_windows * c->feat_frames * ZK_NMEL * 4);
+  return ZK_OK;
+}
+
+int zk_ast_forward(zk_ctx* c, int stage, const float* input_values, const int32_t* win_idx, int32_t B, float* logits) {
+  int rc = check_stage(c, stage);
+  if (rc) return rc;
+  if (B < 0) return fail(c, ZK_E_ARG, "B < 0");
+  if (B == 0) return ZK_OK;
+  if (!logits) return fail(c, ZK_E_ARG, "logits is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  StageModel& sm = c->model[stage];
+  const void* d_in = nullptr;
+  const void* d_idx = nullptr;
+  if (input_values) {
+    if ((rc = to_device(c, input_values, (size_t)B * ZK_MAXLEN * ZK_NMEL * 4, c->st_in, &d_in))) return rc;
+  } else {
+    if (c->feat_windows <= 0) return fail(c, ZK_E_STATE, "input_values is NULL and the feature slot is empty (zk_logmel)");
+    if (!win_idx && B > c->feat_windows) return fail(c, ZK_E_SHAPE, "B=%d exceeds the %d windows in the feature slot", B, c->feat_windows);
+    if (win_idx && (rc = to_device(c, win_idx, (size_t)B * 4, c->st_idx, &d_idx))) return rc;
+  }
+  const size_t lbytes = (size_t)B * sm.num_labels * 4;
+  const bool dev_out = is_device_ptr(logits);
+  float* d_logits = logits;
+  if (!dev_out) { HIPCHK(c, c->st_out.ensure(lbytes)); d_logits = c->st_out.as<float>(); }
+  if ((rc = forward_device(c, stage, (const float*)d_in, (const int32_t*)d_idx, B, d_logits))) return rc;
+  if (!dev_out) return from_device(c, d_logits, logits, lbytes);
+  return finish(c);
+}
+
+int zk_softmax(zk_ctx* c, const float* logits, int32_t n, int32_t num_labels, float* probs) {
+  if (!c || !logits || !probs) return ZK_E_ARG;
+  if (n <= 0) return ZK_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)n * num_labels * 4;
+  const void* d_in = nullptr;
+  int rc = to_device(c, logits, bytes, c->st_in, &d_in);
+  if (rc) return rc;
+  const bool dev = is_device_ptr(probs);
+  float* d_out = probs;
+  if (!dev) { HIPCHK(c, c->st_out.ensure(bytes)); d_out = c->st_out.as<float>(); }
+  zk_launch_softmax2((const float*)d_in, n, num_labels, d_out, c->stream);
+  HIPCHK(c, hipGetLastError());
+  if (!dev) return from_device(c, d_out, probs, bytes);
+  return finish(c);
+}
+
+int zk_gate(zk_ctx* c, const float* logits, int32_t n, float thr1, float fwd_min_prob, float* probs, int32_t* idx,
+            int32_t* cnt) {
+  if (!c || !logits || !idx || !cnt) return ZK_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (n <= 0) {
+    const int32_t z = 0;
+    if (is_device_ptr(cnt)) HIPCHK(c, hipMemcpy(cnt, &z, 4, hipMemcpyHostToDevice));
+    else *cnt = 0;
+    return ZK_OK;
+  }
+  const void* d_in = nullptr;
+  int rc = to_device(c, logits, (size_t)n * 8, c->st_in, &d_in);
+  if (rc) return rc;
+  HIPCHK(c, c->gate_idx.ensure((size_t)n * 4));
+  HIPCHK(c, c->gate_cnt.ensure(16));
+  float* d_probs = nullptr;
+  const bool pdev = probs && is_device_ptr(probs);
+  if (probs) { if (pdev) d_probs = probs; else { HIPCHK(c, c->st_out.ensure((size_t)n * 8)); d_probs = c->st_out.as<float>(); } }
+  zk_launch_gate((const float*)d_in, n, thr1, fwd_min_prob, d_probs, c->gate_idx.as<int32_t>(), c->gate_cnt.as<int32_t>(), c->stream);
+  HIPCHK(c, hipGetLastError());
+  if (probs && !pdev && (rc = from_device(c, d_probs, probs, (size_t)n * 8))) return rc;
+  if ((rc = from_device(c, c->gate_cnt.p, cnt, 4))) return rc;
+  if ((rc = from_device(c, c->gate_idx.p, idx, (size_t)n * 4))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ZK_OK;
+}
+
+int zk_two_stage(zk_ctx* c, const float* audio, int64_t n_samples, int64_t first_start, int64_t hop, int32_t win,
+                 int32_t N, float thr1, float fwd_min_prob, float* s1_logits, int32_t* swallow_idx, int32_t* n_swallow,
+                 float* s2_logits) {
+  int rc = check_stage(c, 0);
+  if (!rc) rc = check_stage(c, 1);
+  if (rc) return rc;
+  if (!s1_logits || !swallow_idx || !n_swallow || !s2_logits) return fail(c, ZK_E_ARG, "NULL output");
+  if (c->model[0].num_labels != 2 || c->model[1].num_labels != 2) return fail(c, ZK_E_SHAPE, "cascade needs 2-label heads");
+  if (N <= 0) { int32_t z = 0; if (is_device_ptr(n_swallow)) HIPCHK(c, hipMemcpy(n_swallow, &z, 4, hipMemcpyHostToDevice)); else *n_swallow = 0; return ZK_OK; }
+  const bool was_async = c->async;
+  c->async = true;
+  rc = zk_logmel(c, audio, n_samples, first_start, hop, win, N);
+  c->async = was_async;
+  if (rc) return rc;
+  HIPCHK(c, c->s1_logits.ensure((size_t)N * 8));
+  HIPCHK(c, c->s2_logits.ensure((size_t)N * 8));
+  HIPCHK(c, c->gate_idx.ensure((size_t)N * 4));
+  HIPCHK(c, c->gate_cnt.ensure(16));
+  if ((rc = forward_device(c, 0, nullptr, nullptr, N, c->s1_logits.as<float>()))) return rc;
+  zk_launch_gate(c->s1_logits.as<float>(), N, thr1, fwd_min_prob, nullptr, c->gate_idx.as<int32_t>(),
+                 c->gate_cnt.as<int32_t>(), c->stream);
+  HIPCHK(c, hipGetLastError());
+  int32_t K = 0;
+  HIPCHK(c, hipMemcpyAsync(&K, c->gate_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the only host sync of the cascade: K sizes the stage-2 grid
+  if (K > 0 && (rc = forward_device(c, 1, nullptr, c->gate_idx.as<int32_t>(), K, c->s2_logits.as<float>()))) return rc;
+  if ((rc = from_device(c, c->s1_logits.p, s1_logits, (size_t)N * 8))) return rc;
+  if ((rc = from_device(c, c->gate_idx.p, swallow_idx, (size_t)K * 4))) return rc;
+  if (K > 0 && (rc = from_device(c, c->s2_logits.p, s2_logits, (size_t)K * 8))) return rc;
+  if (is_device_ptr(n_swallow)) HIPCHK(c, hipMemcpyAsync(n_swallow, c->gate_cnt.p, 4, hipMemcpyDeviceToDevice, c->stream));
+  else *n_swallow = K;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ZK_OK;
+}
+
+int zk_resample(zk_ctx* c, const float* in, int64_t n_in, int32_t orig_sr, int32_t new_sr, float* out, int64_t n_out) {
+  if (!c || !in || !out) return ZK_E_ARG;
+  if (orig_sr <= 0 || new_sr <= 0 || n_in <= 0) return fail(c, ZK_E_ARG, "bad resample arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  int a = orig_sr, b = new_sr;
+  while (b) { int t = a % b; a = b; b = t; }
+  const int orig = orig_sr / a, neu = new_sr / a;
+  const int64_t want = (neu * n_in + orig - 1) / orig;
+  if (n_out != want) return fail(c, ZK_E_SHAPE, "n_out must be ceil(new*n_in/orig) = %lld", (long long)want);
+  if (orig != c->rs_orig || neu != c->rs_new) {
+    // torchaudio.functional._get_sinc_resample_kernel, sinc_interp_hann, lowpass_filter_width=6, rolloff=0.99
+    const double lpw = 6.0, rolloff = 0.99;
+    const double base_freq = (double)(orig < neu ? orig : neu) * rolloff;
+    const int width = (int)ceil(lpw * orig / base_freq);
+    const int klen = 2 * width + orig;
+    std::vector<float> k((size_t)neu * klen);
+    for (int p = 0; p < neu; ++p)
+      for (int j = 0; j < klen; ++j) {
+        double t = ((double)(-p) / neu + (double)(j - width) / orig) * base_freq;
+        if (t < -lpw) t = -lpw;
+        if (t > lpw) t = lpw;
+        const double wdw = cos(t * M_PI / lpw / 2.0);
+        const double tt = t * M_PI;
+        const double sinc = tt == 0.0 ? 1.0 : sin(tt) / tt;
+        k[(size_t)p * klen + j] = (float)(sinc * wdw * wdw * (base_freq / orig));
+      }
+    HIPCHK(c, c->rs_kern.ensure(k.size() * 4));
+    HIPCHK(c, hipMemcpy(c->rs_kern.p, k.data(), k.size() * 4, hipMemcpyHostToDevice));
+    c->rs_orig = orig; c->rs_new = neu; c->rs_width = width; c->rs_klen = klen;
+  }
+  const void* d_in = nullptr;
+  int rc = to_device(c, in, (size_t)n_in * 4, c->st_in, &d_in);
+  if (rc) return rc;
+  const bool dev = is_device_ptr(out);
+  float* d_out = out;
+  if (!dev) { HIPCHK(c, c->st_out.ensure((size_t)n_out * 4)); d_out = c->st_out.as<float>(); }
+  zk_launch_resample((const float*)d_in, n_in, orig, neu, c->rs_width, c->rs_kern.as<float>(), c->rs_klen, d_out, n_out, c->stream);
+  HIPCHK(c, hipGetLastError());
+  if (!dev) return from_device(c, d_out, out, (size_t)n_out * 4);
+  return finish(c);
+}
+
+// ---- measurement ------------------------------------------------------------------------------------------------
+int zk_prof_begin(zk_ctx* c) {
+  if (!c) return ZK_E_ARG;
+  c->prof = true;
+  c->ev_used.clear();
+  for (int i = 0; i < P_N; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  return ZK_OK;
+}
+int zk_prof_end(zk_ctx* c) {
+  if (!c) return ZK_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& u : c->ev_used) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_pool[u.second].first, c->ev_pool[u.second].second) == hipSuccess) {
+      c->prof_ms[u.first] += ms;
+      c->prof_n[u.first] += 1;
+    }
+  }
+  c->ev_used.clear();
+  c->prof = false;
+  return ZK_OK;
+}
+int zk_prof_get(zk_ctx* c, const char* name, double* ms, int64_t* launches) {
+  if (!c || !name) return ZK_E_ARG;
+  for (int i = 0; i < P_N; ++i)
+    if (!strcmp(name, kProfNames[i])) { if (ms) *ms = c->prof_ms[i]; if (launches) *launches = c->prof_n[i]; return ZK_OK; }
+  return fail(c, ZK_E_ARG, "unknown profile class '%s'", name);
+}
+
+int zk_debug_set_tap(zk_ctx* c, int32_t layer) { if (!c) return ZK_E_ARG; c->tap_layer = layer; c->tap_windows = 0; return ZK_OK; }
+int zk_debug_get_tap(zk_ctx* c, float* out, int32_t n_windows) {
+  if (!c || !out) return ZK_E_ARG;
+  if (n_windows > c->tap_windows) return fail(c, ZK_E_STATE, "tap holds %d windows, %d requested", c->tap_windows, n_windows);
+  return from_device(c, c->tap.p, out, (size_t)n_windows * ZK_SEQ * ZK_HIDDEN * 4);
+}
+
+// ---- test hooks: run ONE kernel on caller-provided fp32 host data (tests/test_kernels_gpu.py) -------------------------
+int zk_test_layernorm(zk_ctx* c, const float* x, const float* gamma, const float* beta, int32_t rows, float eps,
+                      int32_t nsplit, float* out) {
+  if (!c) return ZK_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)rows * ZK_HIDDEN;
+  float *dx, *dg, *db; half_t *hi, *lo;
+  HIPCHK(c, hipMalloc((void**)&dx, n * 4)); HIPCHK(c, hipMalloc((void**)&dg, ZK_HIDDEN * 4)); HIPCHK(c, hipMalloc((void**)&db, ZK_HIDDEN * 4));
+  HIPCHK(c, hipMalloc((void**)&hi, n * 2)); HIPCHK(c, hipMalloc((void**)&lo, n * 2));
+  HIPCHK(c, hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dg, gamma, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(db, beta, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
+  zk_launch_layernorm(dx, ZK_HIDDEN, dg, db, rows, zk_planes{hi, nsplit == 3 ? lo : nullptr}, eps, c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<uint16_t> h(n), l(n, 0);
+  HIPCHK(c, hipMemcpy(h.data(), hi, n * 2, hipMemcpyDeviceToHost));
+  if (nsplit == 3) HIPCHK(c, hipMemcpy(l.data(), lo, n * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) out[i] = half_bits_to_float(h[i]) + (nsplit == 3 ? half_bits_to_float(l[i]) : 0.f);
+  (void)hipFree(dx); (void)hipFree(dg); (void)hipFree(db); (void)hipFree(hi); (void)hipFree(lo);
+  return ZK_OK;
+}
+
+// x [M,K], w [N,K], bias [N] fp32 host.  epi STORE/GELU: out [M,N] = planes summed.  RESID: out [M,N] in/out.
+// PATCH: M must be a multiple of 1212, pos [1214,N], out [(M/1212)*1214, N] (rows 0,1 of each window untouched).
+int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, int32_t M, int32_t N, int32_t K,
+                 int32_t epi, int32_t nsplit, const float* pos, float* out) {
+  if (!c) return ZK_E_ARG;
+  if (N % 256 || K % 64 || M < 1) return fail(c, ZK_E_SHAPE, "zk_test_gemm: need N%%256==0, K%%64==0");
+  if (epi == ZK_EPI_PATCH && (M % ZK_NPATCH || N != ZK_HIDDEN)) return fail(c, ZK_E_SHAPE, "PATCH epilogue: M%%1212==0, N==768");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nx = (size_t)M * K, nw = (size_t)N * K;
+  const size_t orows = epi == ZK_EPI_PATCH ? (size_t)(M / ZK_NPATCH) * ZK_SEQ : (size_t)M;
+  const size_t no = orows * N;
+  float *dx, *dw, *dbias, *dres = nullptr, *dpos = nullptr; half_t *xh, *xl, *wh, *wl, *oh = nullptr, *ol = nullptr;
+  HIPCHK(c, hipMalloc((void**)&dx, nx * 4)); HIPCHK(c, hipMalloc((void**)&dw, nw * 4)); HIPCHK(c, hipMalloc((void**)&dbias, (size_t)N * 4));
+  HIPCHK(c, hipMalloc((void**)&xh, nx * 2)); HIPCHK(c, hipMalloc((void**)&xl, nx * 2));
+  HIPCHK(c, hipMalloc((void**)&wh, nw * 2)); HIPCHK(c, hipMalloc((void**)&wl, nw * 2));
+  HIPCHK(c, hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dw, w, nw * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+  zk_launch_split_f32(dx, (int64_t)nx, 1.f, xh, xl, c->stream);
+  zk_launch_split_f32(dw, (int64_t)nw, 1.f, wh, wl, c->stream);
+  if (epi == ZK_EPI_RESID || epi == ZK_EPI_PATCH) {
+    HIPCHK(c, hipMalloc((void**)&dres, no * 4));
+    HIPCHK(c, hipMemcpy(dres, out, no * 4, hipMemcpyHostToDevice));
+    if (epi == ZK_EPI_PATCH) { HIPCHK(c, hipMalloc((void**)&dpos, (size_t)ZK_SEQ * N * 4)); HIPCHK(c, hipMemcpy(dpos, pos, (size_t)ZK_SEQ * N * 4, hipMemcpyHostToDevice)); }
+  } else {
+    HIPCHK(c, hipMalloc((void**)&oh, no * 2)); HIPCHK(c, hipMalloc((void**)&ol, no * 2));
+    HIPCHK(c, hipMemset(ol, 0, no * 2));
+  }
+  zk_gemm_args a;
+  a.x_hi = xh; a.x_lo = nsplit == 3 ? xl : nullptr; a.w_hi = wh; a.w_lo = nsplit == 3 ? wl : nullptr; a.bias = dbias;
+  a.M = M; a.N = N; a.K = K; a.o_hi = oh; a.o_lo = nsplit == 3 ? ol : nullptr; a.resid = dres; a.pos = dpos; a.lo_n_limit = N;
+  zk_launch_gemm(a, epi, nsplit, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (dres) HIPCHK(c, hipMemcpy(out, dres, no * 4, hipMemcpyDeviceToHost));
+  else {
+    std::vector<uint16_t> h(no), l(no);
+    HIPCHK(c, hipMemcpy(h.data(), oh, no * 2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(l.data(), ol, no * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < no; ++i) out[i] = half_bits_to_float(h[i]) + half_bits_to_float(l[i]);
+  }
+  for (void* p : {(void*)dx, (void*)dw, (void*)dbias, (void*)dres, (void*)dpos, (void*)xh, (void*)xl, (void*)wh, (void*)wl, (void*)oh, (void*)ol})
+    if (p) (void)hipFree(p);
+  return ZK_OK;
+}
+
+// qkv fp32 host [W*1214, 2304] -> out fp32 host [W*1214, 768]
+int zk_test_attention(zk_ctx* c, const float* qkv, int32_t W, int32_t nsplit, float* out) {
+  if (!c) return ZK_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t rows = (size_t)W * ZK_SEQ, nq = rows * 3 * ZK_HIDDEN, no = rows * ZK_HIDDEN;
+  float* dq; half_t *qh, *ql, *oh, *ol;
+  HIPCHK(c, hipMalloc((void**)&dq, nq * 4)); HIPCHK(c, hipMalloc((void**)&qh, nq * 2)); HIPCHK(c, hipMalloc((void**)&ql, nq * 2));
+  HIPCHK(c, hipMalloc((void**)&oh, no * 2)); HIPCHK(c, hipMalloc((void**)&ol, no * 2));
+  HIPCHK(c, hipMemset(ol, 0, no * 2));
+  HIPCHK(c, hipMemcpy(dq, qkv, nq * 4, hipMemcpyHostToDevice));
+  zk_launch_split_f32(dq, (int64_t)nq, 1.f, qh, ql, c->stream);
+  zk_launch_attention(zk_planes{qh, nsplit == 3 ? ql : nullptr}, zk_planes{oh, nsplit == 3 ? ol : nullptr}, W, nsplit, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<uint16_t> h(no), l(no);
+  HIPCHK(c, hipMemcpy(h.data(), oh, no * 2, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(l.data(), ol, no * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < no; ++i) out[i] = half_bits_to_float(h[i]) + half_bits_to_float(l[i]);
+  (void)hipFree(dq); (void)hipFree(qh); (void)hipFree(ql); (void)hipFree(oh); (void)hipFree(ol);
+  return ZK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+"""ctypes binding of libzkast.so (the C ABI in include/zkast.h).
+
+This is the whole boundary between the Python host code and the HIP kernels: plain pointers and sizes, no torch
+types.  There is NO CPU fallback: if the shared library is missing or no gfx950 GPU is visible every entry point
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkast.so")
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+
+ZK_F16, ZK_F16X3 = 1, 3
+ZK_DT_F32, ZK_DT_F16, ZK_DT_BF16 = 0, 1, 2
+EPI_STORE, EPI_GELU, EPI_RESID, EPI_PATCH = 0, 1, 2, 3
+COMPUTE_MODES = {"f16": ZK_F16, "f16x3": ZK_F16X3, 1: ZK_F16, 3: ZK_F16X3}
+
+# every symbol include/zkast.h declares (tests/test_abi.py checks the .so exports exactly these)
+SYMBOLS = [
+    "zk_create", "zk_destroy", "zk_last_error", "zk_set_stream", "zk_set_async", "zk_synchronize",
+    "zk_set_micro_batch", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_fx",
+    "zk_logmel", "zk_features_expand", "zk_features_get", "zk_ast_forward", "zk_softmax", "zk_two_stage", "zk_gate",
+    "zk_resample", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_debug_set_tap", "zk_debug_get_tap",
+    "zk_test_layernorm", "zk_test_gemm", "zk_test_attention",
+]
+
+
+class ZkError(RuntimeError):
+    pass
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+                ("dtype", C.c_int32)]
+
+
+class ASTConfigC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("hidden_size", "num_hidden_layers", "num_attention_heads",
+                                         "intermediate_size", "patch_size", "frequency_stride", "time_stride",
+                                         "max_length", "num_mel_bins", "num_labels")] + [("layer_norm_eps", C.c_float)]
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into libzkast.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["bash", os.path.join(CSRC, "build.sh")], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout, r.stderr)
+    if r.returncode:
+        raise ZkError("building libzkast.so failed:\n" + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ZkError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(zkast has no CPU fallback; the HIP library is the product)")
+        lib = C.CDLL(LIB_PATH)
+        vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+        sig = {
+            "zk_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+            "zk_destroy": (None, [vp]),
+            "zk_last_error": (C.c_char_p, [vp]),
+            "zk_set_stream": (C.c_int, [vp, vp]),
+            "zk_set_async": (C.c_int, [vp, C.c_int]),
+            "zk_synchronize": (C.c_int, [vp]),
+            "zk_set_micro_batch": (C.c_int, [vp, i32]),
+            "zk_version": (C.c_char_p, []),
+            "zk_model_load": (C.c_int, [vp, C.c_int, C.POINTER(TensorDesc), i32, C.POINTER(ASTConfigC), f32, f32, i32]),
+            "zk_model_set_compute_mode": (C.c_int, [vp, C.c_int, i32]),
+            "zk_model_set_fx": (C.c_int, [vp, C.c_int, f32, f32]),
+            "zk_logmel": (C.c_int, [vp, vp, i64, i64, i64, i32, i32]),
+            "zk_features_expand": (C.c_int, [vp, f32, f32, i32, vp]),
+            "zk_features_get": (C.c_int, [vp, vp, C.POINTER(i32), C.POINTER(i32)]),
+            "zk_ast_forward": (C.c_int, [vp, C.c_int, vp, vp, i32, vp]),
+            "zk_softmax": (C.c_int, [vp, vp, i32, i32, vp]),
+            "zk_two_stage": (C.c_int, [vp, vp, i64, i64, i64, i32, i32, f32, f32, vp, vp, vp, vp]),
+            "zk_gate": (C.c_int, [vp, vp, i32, f32, f32, vp, vp, vp]),
+            "zk_resample": (C.c_int, [vp, vp, i64, i32, i32, vp, i64]),
+            "zk_prof_begin": (C.c_int, [vp]),
+            "zk_prof_end": (C.c_int, [vp]),
+            "zk_prof_get": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
+            "zk_debug_set_tap": (C.c_int, [vp, i32]),
+            "zk_debug_get_tap": (C.c_int, [vp, vp, i32]),
+            "zk_test_layernorm": (C.c_int, [vp, vp, vp, vp, i32, f32, i32, vp]),
+            "zk_test_gemm": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+            "zk_test_attention": (C.c_int, [vp, vp, i32, i32, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    """(address, keepalive) of a C-contiguous numpy array or torch tensor (host or device)."""
+    if x is None:
+        return None, None
+    if _is_torch(x):
+        if not x.is_contiguous():
+            x = x.contiguous()
+        return x.data_ptr(), x
+    a = np.ascontiguousarray(x)
+    return a.ctypes.data, a
+
+
+PROF_CLASSES = ["gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention", "layernorm", "logmel",
+                "embed", "head"]
+
+
+class Context:
+    """One (process, GPU) context: weights of the two stages, the feature slot, workspace and a HIP stream."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.zk_create(int(device), C.byref(h))
+        if rc:
+            raise ZkError(f"zk_create({device}) failed ({rc}): {self.lib.zk_last_error(None).decode()}")
+        self.h = h
+        self.device = int(device)
+        self.stage_labels = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            raise ZkError(f"{what} failed ({rc}): {self.lib.zk_last_error(self.h).decode()}")
+
+    # ---- configuration ----
+    def set_micro_batch(self, windows: int):
+        self._chk(self.lib.zk_set_micro_batch(self.h, int(windows)), "zk_set_micro_batch")
+
+    def set_stream(self, hip_stream: int | None):
+        self._chk(self.lib.zk_set_stream(self.h, C.c_void_p(hip_stream or 0)), "zk_set_stream")
+
+    def set_async(self, enable: bool):
+        self._chk(self.lib.zk_set_async(self.h, int(bool(enable))), "zk_set_async")
+
+    def synchronize(self):
+        self._chk(self.lib.zk_synchronize(self.h), "zk_synchronize")
+
+    # ---- model ----
+    def load_model(self, stage: int, state_dict: dict, config: dict, fx_mean: float, fx_std: float, compute_mode=ZK_F16X3):
+        descs = (TensorDesc * len(state_dict))()
+        keep = []
+        for i, (name, arr) in enumerate(state_dict.items()):
+            if _is_torch(arr):
+                import torch
+                t = arr.detach().cpu().contiguous()
+                if t.dtype == torch.bfloat16:
+                    a, dt = t.view(torch.int16).numpy(), ZK_DT_BF16
+                elif t.dtype == torch.float16:
+                    a, dt = t.numpy(), ZK_DT_F16
+                else:
+                    a, dt = t.float().numpy(), ZK_DT_F32
+            else:
+                a = np.ascontiguousarray(arr)
+                if a.dtype == np.float16:
+                    dt = ZK_DT_F16
+                else:
+                    a, dt = np.ascontiguousarray(a, dtype=np.float32), ZK_DT_F32
+            nb = name.encode()
+            keep.append((a, nb))
+            d = descs[i]
+            d.name = nb
+            d.data = a.ctypes.data
+            d.ndim = min(a.ndim, 4) if a.ndim <= 4 else 4
+            shp = list(a.shape) if a.ndim <= 4 else [int(np.prod(a.shape[:-3]))] + list(a.shape[-3:])
+            for j in range(4):
+                d.shape[j] = shp[j] if j < len(shp) else 1
+            d.dtype = dt
+        cfg = ASTConfigC()
+        defaults = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                        patch_size=16, frequency_stride=10, time_stride=10, max_length=1024, num_mel_bins=128,
+                        num_labels=2)
+        for k, v in defaults.items():
+            setattr(cfg, k, int(config.get(k, v)))
+        cfg.layer_norm_eps = float(config.get("layer_norm_eps", 1e-12))
+        mode = COMPUTE_MODES[compute_mode]
+        self._chk(self.lib.zk_model_load(self.h, int(stage), descs, len(state_dict), C.byref(cfg), float(fx_mean),
+                                         float(fx_std), mode), f"zk_model_load(stage={stage})")
+        self.stage_labels[int(stage)] = int(cfg.num_labels)
+
+    def set_compute_mode(self, stage: int, mode):
+        self._chk(self.lib.zk_model_set_compute_mode(self.h, int(stage), COMPUTE_MODES[mode]), "zk_model_set_compute_mode")
+
+    def set_fx(self, stage: int, mean: float, std: float):
+        self._chk(self.lib.zk_model_set_fx(self.h, int(stage), float(mean), float(std)), "zk_model_set_fx")
+
+    # ---- features ----
+    def logmel(self, audio, n_samples: int, first_start: int, hop: int, win: int, n_windows: int):
+        p, _k = _ptr(audio)
+        self._chk(self.lib.zk_logmel(self.h, p, int(n_samples), int(first_start), int(hop), int(win), int(n_windows)),
+                  "zk_logmel")
+
+    def features_expand(self, mean: float, std: float, do_normalize: bool, out):
+        p, _k = _ptr(out)
+        self._chk(self.lib.zk_features_expand(self.h, float(mean), float(std), int(bool(do_normalize)), p),
+                  "zk_features_expand")
+
+    def features_shape(self):
+        nw, nf = C.c_int32(), C.c_int32()
+        self._chk(self.lib.zk_features_get(self.h, None, C.byref(nw), C.byref(nf)), "zk_features_get")
+        return nw.value, nf.value
+
+    def features_get(self) -> np.ndarray:
+        nw, nf = self.features_shape()
+        out = np.empty((nw, nf, 128), dtype=np.float32)
+        if nw:
+            self._chk(self.lib.zk_features_get(self.h, out.ctypes.data, None, None), "zk_features_get")
+        return out
+
+    # ---- transformer ----
+    def ast_forward(self, stage: int, input_values, win_idx, B: int, logits_out):
+        pi, _k1 = _ptr(input_values)
+        px, _k2 = _ptr(win_idx)
+        po, _k3 = _ptr(logits_out)
+        self._chk(self.lib.zk_ast_forward(self.h, int(stage), pi, px, int(B), po), "zk_ast_forward")
+
+    def softmax(self, logits: np.ndarray) -> np.ndarray:
+        logits = np.ascontiguousarray(logits, dtype=np.float32)
+        out = np.empty_like(logits)
+        if logits.size:
+            self._chk(self.lib.zk_softmax(self.h, logits.ctypes.data, logits.shape[0], logits.shape[1], out.ctypes.data),
+                      "zk_softmax")
+        return out
+
+    def gate(self, logits: np.ndarray, thr1: float, fwd_min_prob=None):
+        logits = np.ascontiguousarray(logits, dtype=np.float32)
+        n = logits.shape[0]
+        probs = np.empty((n, 2), np.float32)
+        idx = np.empty((max(n, 1),), np.int32)
+        cnt = C.c_int32(0)
+        self._chk(self.lib.zk_gate(self.h, logits.ctypes.data, n, float(thr1),
+                                   -1.0 if fwd_min_prob is None else float(fwd_min_prob), probs.ctypes.data,
+                                   idx.ctypes.data, C.addressof(cnt)), "zk_gate")
+        return probs, idx[: cnt.value].copy()
+
+    def two_stage(self, audio, n_samples, first_start, hop, win, n_windows, thr1, fwd_min_prob=None):
+        pa, _k = _ptr(audio)
+        n = int(n_windows)
+        s1 = np.empty((n, 2), np.float32)
+        s2 = np.empty((max(n, 1), 2), np.float32)
+        idx = np.empty((max(n, 1),), np.int32)
+        cnt = C.c_int32(0)
+        self._chk(self.lib.zk_two_stage(self.h, pa, int(n_samples), int(first_start), int(hop), int(win), n,
+                                        float(thr1), -1.0 if fwd_min_prob is None else float(fwd_min_prob),
+                                        s1.ctypes.data, idx.ctypes.data, C.addressof(cnt), s2.ctypes.data),
+                  "zk_two_stage")
+        k = cnt.value
+        return s1, idx[:k].copy(), s2[:k].copy()
+
+    def resample(self, audio: np.ndarray, orig_sr: int, new_sr: int) -> np.ndarray:
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        g = int(np.gcd(orig_sr, new_sr))
+        o, nw = orig_sr // g, new_sr // g
+        n_out = (nw * audio.shape[0] + o - 1) // o
+        out = np.empty((n_out,), np.float32)
+        self._chk(self.lib.zk_resample(self.h, audio.ctypes.data, audio.shape[0], int(orig_sr), int(new_sr),
+                                       out.ctypes.data, n_out), "zk_resample")
+        return out
+
+    # ---- measurement ----
+    def prof_begin(self):
+        self._chk(self.lib.zk_prof_begin(self.h), "zk_prof_begin")
+
+    def prof_end(self) -> dict:
+        self._chk(self.lib.zk_prof_end(self.h), "zk_prof_end")
+        out = {}
+        for name in PROF_CLASSES:
+            ms, n = C.c_double(), C.c_int64()
+            self._chk(self.lib.zk_prof_get(self.h, name.encode(), C.byref(ms), C.byref(n)), "zk_prof_get")
+            out[name] = (ms.value, n.value)
+        return out
+
+    def debug_tap(self, layer: int):
+        self._chk(self.lib.zk_debug_set_tap(self.h, int(layer)), "zk_debug_set_tap")
+
+    def debug_get_tap(self, n_windows: int) -> np.ndarray:
+        out = np.empty((n_windows, 1214, 768), np.float32)
+        self._chk(self.lib.zk_debug_get_tap(self.h, out.ctypes.data, int(n_windows)), "zk_debug_get_tap")
+        return out
+
+    # ---- single-kernel test hooks ----
+    def test_layernorm(self, x, gamma, beta, eps, nsplit):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(x)
+        self._chk(self.lib.zk_test_layernorm(self.h, x.ctypes.data, np.ascontiguousarray(gamma, np.float32).ctypes.data,
+                                             np.ascontiguousarray(beta, np.float32).ctypes.data, x.shape[0], float(eps),
+                                             int(nsplit), out.ctypes.data), "zk_test_layernorm")
+        return out
+
+    def test_gemm(self, x, w, bias, epi, nsplit, resid=None, pos=None):
+        x = np.ascontiguousarray(x, np.float32)
+        w = np.ascontiguousarray(w, np.float32)
+        bias = np.ascontiguousarray(bias, np.float32)
+        M, K = x.shape
+        N = w.shape[0]
+        if epi == EPI_PATCH:
+            out = np.ascontiguousarray(resid, np.float32).copy()
+            pos = np.ascontiguousarray(pos, np.float32)
+        elif epi == EPI_RESID:
+            out = np.ascontiguousarray(resid, np.float32).copy()
+        else:
+            out = np.empty((M, N), np.float32)
+        self._chk(self.lib.zk_test_gemm(self.h, x.ctypes.data, w.ctypes.data, bias.ctypes.data, M, N, K, int(epi),
+                                        int(nsplit), None if pos is None else pos.ctypes.data, out.ctypes.data),
+                  "zk_test_gemm")
+        return out
+
+    def test_attention(self, qkv, n_windows, nsplit):
+        qkv = np.ascontiguousarray(qkv, np.float32)
+        out = np.empty((qkv.shape[0], 768), np.float32)
+        self._chk(self.lib.zk_test_attention(self.h, qkv.ctypes.data, int(n_windows), int(nsplit), out.ctypes.data),
+                  "zk_test_attention")
+        return out
+
+
+_contexts: dict = {}
+
+
+def get_context(device: int = 0) -> Context:
+    """Process-wide context per GPU (the reference's module-level DEVICE, src/test_long_audio_windows_2stage.py:48)."""
+    ctx = _contexts.get(device)
+    if ctx is None or ctx.h is None:
+        ctx = Context(device)
+        _contexts[device] = ctx
+    return ctx

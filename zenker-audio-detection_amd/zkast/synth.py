@@ -1,0 +1,175 @@
+"""Deterministic synthetic weights and audio for the AST two-stage path.
+
+No checkpoint of the reference's fine-tuned models exists offline, so tests, fixtures and
+``bench.py`` all draw the 86,190,338 parameters of ``ASTForAudioClassification(ASTConfig(num_labels=2))``
+from a self-contained counter-based PRNG (splitmix64).  Pure integer numpy => bit-identical on every host,
+which is what lets the golden logits in ``tests/golden/`` be regenerated without shipping 345 MB of weights.
+
+Tensor names follow the transformers 5.x state-dict layout
+(``$TF/models/audio_spectrogram_transformer/modeling_audio_spectrogram_transformer.py:38-318``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+HIDDEN = 768
+LAYERS = 12
+HEADS = 12
+INTER = 3072
+PATCH = 16
+FSTRIDE = 10
+TSTRIDE = 10
+N_MEL = 128
+MAX_LEN = 1024
+F_OUT = (N_MEL - PATCH) // FSTRIDE + 1      # 12
+T_OUT = (MAX_LEN - PATCH) // TSTRIDE + 1    # 101
+SEQ = F_OUT * T_OUT + 2                     # 1214
+NUM_LABELS = 2
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _fnv1a64(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def splitmix64_uniform(seed: int, n: int) -> np.ndarray:
+    """n doubles in [0,1): element i is mix(seed + (i+1)*golden) >> 11, scaled by 2^-53."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _tensor(seed: int, name: str, shape, scale: float, offset: float = 0.0) -> np.ndarray:
+    n = int(np.prod(shape))
+    u = splitmix64_uniform(seed ^ _fnv1a64(name), n)
+    # uniform in [-a, a] with a = scale*sqrt(3) has standard deviation `scale`
+    v = (u * 2.0 - 1.0) * (scale * 1.7320508075688772) + offset
+    return v.astype(np.float32).reshape(shape)
+
+
+def ast_param_shapes(num_labels: int = NUM_LABELS) -> dict:
+    p = "audio_spectrogram_transformer."
+    s = {
+        p + "embeddings.cls_token": (1, 1, HIDDEN),
+        p + "embeddings.distillation_token": (1, 1, HIDDEN),
+        p + "embeddings.position_embeddings": (1, SEQ, HIDDEN),
+        p + "embeddings.patch_embeddings.projection.weight": (HIDDEN, 1, PATCH, PATCH),
+        p + "embeddings.patch_embeddings.projection.bias": (HIDDEN,),
+    }
+    for i in range(LAYERS):
+        q = f"{p}layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            s[q + f"attention.{nm}.weight"] = (HIDDEN, HIDDEN)
+            s[q + f"attention.{nm}.bias"] = (HIDDEN,)
+        s[q + "layernorm_before.weight"] = (HIDDEN,)
+        s[q + "layernorm_before.bias"] = (HIDDEN,)
+        s[q + "layernorm_after.weight"] = (HIDDEN,)
+        s[q + "layernorm_after.bias"] = (HIDDEN,)
+        s[q + "mlp.fc1.weight"] = (INTER, HIDDEN)
+        s[q + "mlp.fc1.bias"] = (INTER,)
+        s[q + "mlp.fc2.weight"] = (HIDDEN, INTER)
+        s[q + "mlp.fc2.bias"] = (HIDDEN,)
+    s[p + "layernorm.weight"] = (HIDDEN,)
+    s[p + "layernorm.bias"] = (HIDDEN,)
+    s["classifier.layernorm.weight"] = (HIDDEN,)
+    s["classifier.layernorm.bias"] = (HIDDEN,)
+    s["classifier.dense.weight"] = (num_labels, HIDDEN)
+    s["classifier.dense.bias"] = (num_labels,)
+    return s
+
+
+# Weight "sets": (matrix std, bias std, embedding std, LN gamma jitter, LN beta std, head std)
+WEIGHT_SETS = {
+    # HF initializer_range, but with cls/dist/pos randomised too (HF zeroes them,
+    # modeling_audio_spectrogram_transformer.py:246-253) so that every term is exercised.
+    "init": dict(mat=0.02, bias=0.02, emb=0.02, gamma=0.10, beta=0.05, head=0.05, patch=0.02),
+    # wider matrices: peaked attention, residual growth, input-sensitive logits ("trained-like" scale)
+    "wide": dict(mat=0.05, bias=0.05, emb=0.05, gamma=0.25, beta=0.10, head=0.10, patch=0.05),
+}
+
+
+def make_ast_weights(seed: int, weight_set: str = "wide", num_labels: int = NUM_LABELS, layers=None) -> dict:
+    """Full state dict {name: float32 ndarray}.  `layers` (iterable) restricts which encoder layers are built."""
+    ws = WEIGHT_SETS[weight_set]
+    out = {}
+    for name, shape in ast_param_shapes(num_labels).items():
+        if layers is not None and ".layers." in name:
+            li = int(name.split(".layers.")[1].split(".")[0])
+            if li not in layers:
+                continue
+        if name.endswith("layernorm.weight") or name.endswith("layernorm_before.weight") or name.endswith(
+            "layernorm_after.weight"
+        ):
+            out[name] = _tensor(seed, name, shape, ws["gamma"], 1.0)
+        elif "layernorm" in name and name.endswith(".bias"):
+            out[name] = _tensor(seed, name, shape, ws["beta"])
+        elif name.endswith(".bias"):
+            out[name] = _tensor(seed, name, shape, ws["bias"])
+        elif "embeddings.cls_token" in name or "distillation_token" in name or "position_embeddings" in name:
+            out[name] = _tensor(seed, name, shape, ws["emb"])
+        elif "patch_embeddings.projection.weight" in name:
+            out[name] = _tensor(seed, name, shape, ws["patch"])
+        elif name.startswith("classifier.dense"):
+            out[name] = _tensor(seed, name, shape, ws["head"])
+        else:
+            out[name] = _tensor(seed, name, shape, ws["mat"])
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# synthetic audio
+# --------------------------------------------------------------------------------------------------
+SR = 16000
+
+
+def golden_windows() -> np.ndarray:
+    """The six 1 s windows pinned by the log-mel fixture (tests/golden/fbank.npz)."""
+    rng = np.random.default_rng(1234)
+    t = np.arange(SR, dtype=np.float64) / SR
+    w = np.zeros((6, SR), dtype=np.float32)
+    w[0] = rng.normal(0.0, 0.1, SR).astype(np.float32)
+    w[1] = (0.5 * np.sin(2 * np.pi * 440.0 * t)).astype(np.float32)
+    w[2] = (0.3 * np.sin(2 * np.pi * (100.0 * t + 0.5 * 7000.0 * t * t))).astype(np.float32)  # 100→7100 Hz chirp
+    w[3] = 0.0
+    w[4, :5000] = rng.normal(0.0, 0.2, 5000).astype(np.float32)
+    w[5] = rng.normal(0.0, 1e-4, SR).astype(np.float32)  # sits on the mel floor
+    return w
+
+
+def synth_recording(seed: int, n_samples: int, burst_rate_hz: float = 0.2) -> np.ndarray:
+    """N(0, 0.1^2) noise plus 0.3 s chirp bursts (amp 0.5, 150-1200 Hz) at a Poisson rate."""
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0.0, 0.1, n_samples).astype(np.float32)
+    dur = n_samples / SR
+    n_bursts = rng.poisson(burst_rate_hz * dur)
+    blen = int(0.3 * SR)
+    tb = np.arange(blen, dtype=np.float64) / SR
+    for _ in range(int(n_bursts)):
+        s = int(rng.integers(0, max(1, n_samples - blen)))
+        f0 = rng.uniform(150.0, 600.0)
+        f1 = rng.uniform(600.0, 1200.0)
+        ph = 2 * np.pi * (f0 * tb + 0.5 * (f1 - f0) / 0.3 * tb * tb)
+        env = np.hanning(blen)
+        seg = (0.5 * env * np.sin(ph)).astype(np.float32)
+        e = min(n_samples, s + blen)
+        x[s:e] += seg[: e - s]
+    return x
+
+
+def synth_windows(seed: int, n_windows: int) -> np.ndarray:
+    """(n_windows, 16000) fp32: 1 s / 0.5 s-hop windows cut from one synthetic recording."""
+    n_samples = SR + (n_windows - 1) * (SR // 2)
+    x = synth_recording(seed, n_samples)
+    idx = np.arange(n_windows)[:, None] * (SR // 2) + np.arange(SR)[None, :]
+    return x[idx]
