@@ -1,0 +1,184 @@
+"""End-to-end parity on a real MI355X: the HIP path (through the C ABI and the drop-in Python objects) against the
+golden fixtures produced by the real transformers classes + the reference's own functions (tests/golden/), and
+against the CPU oracle on seeded inputs.  Tolerance on logits: 1e-3 max-abs (BASELINE.json north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ast_oracle as orc  # noqa: E402  (checker only)
+
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return {
+        "model": np.load(os.path.join(golden_dir, "model.npz")),
+        "fbank": np.load(os.path.join(golden_dir, "fbank.npz")),
+        "cascade": np.load(os.path.join(golden_dir, "cascade.npz")),
+        "cases": json.load(open(os.path.join(golden_dir, "cascade_cases.json"))),
+    }
+
+
+def _model(seed, wset, stage, mode="f16x3", shift=None, mean=-1.1509622, std=3.5340312):
+    from zkast import ZkASTConfig, ZkASTForAudioClassification, synth
+    sd = synth.make_ast_weights(seed, wset)
+    if shift is not None:
+        sd["classifier.dense.bias"] = sd["classifier.dense.bias"].copy()
+        sd["classifier.dense.bias"][1] += np.float32(shift)
+    return ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd, stage=stage, compute_mode=mode,
+                                       fx_mean=mean, fx_std=std), sd
+
+
+def test_feature_extractor_contract(G):
+    from zkast import ZkASTFeatureExtractor, synth
+    fb = G["fbank"]
+    fx = ZkASTFeatureExtractor(mean=float(fb["mean"]), std=float(fb["std"]))
+    wins = synth.golden_windows()
+    out = fx(list(wins), sampling_rate=16000, return_tensors="pt")
+    x = out[fx.model_input_names[0]]
+    assert tuple(x.shape) == (6, 1024, 128) and str(x.dtype) == "torch.float32"
+    x = x.numpy()
+    assert np.abs(x[:, :98] - fb["norm_rows"]).max() <= 5e-6
+    assert np.all(x[:, 98:] == fb["norm_pad_value"])
+    raw = ZkASTFeatureExtractor(mean=0.0, std=1.0, do_normalize=False)(wins, sampling_rate=16000, return_tensors="np")
+    assert np.abs(raw["input_values"][:, :98] - fb["raw_rows"]).max() <= 2e-5
+    assert np.all(raw["input_values"][:, 98:] == 0.0)
+    with pytest.raises(ValueError, match="sampling rate"):
+        fx(list(wins[:1]), sampling_rate=8000)
+    # single un-batched waveform -> batch of one; ragged lengths in one call
+    one = fx(wins[0], sampling_rate=16000, return_tensors="np")["input_values"]
+    assert one.shape == (1, 1024, 128) and np.array_equal(one[0], x[0])
+    rag = raw.__class__  # noqa: F841
+    r2 = ZkASTFeatureExtractor(do_normalize=False)([wins[0][:4000], np.concatenate([wins[0], wins[2]])],
+                                                   sampling_rate=16000, return_tensors="np")["input_values"]
+    assert int((np.abs(r2[0]).sum(1) != 0).sum()) == int(fb["short_n"])
+    assert np.abs(r2[0][:30] - fb["short_rows"]).max() <= 2e-5
+    assert int((np.abs(r2[1]).sum(1) != 0).sum()) == int(fb["long_n"])
+    assert np.abs(r2[1][:198:9] - fb["long_rows"]).max() <= 2e-5
+
+
+@pytest.mark.parametrize("tag,seed", [("wide", 11), ("init", 12)])
+def test_model_logits_and_checkpoints_vs_golden(G, tag, seed):
+    from zkast import lib
+    g, fb = G["model"], G["fbank"]
+    feats = orc.extract_features(__import__("zkast").synth.golden_windows()[[0, 1, 2, 4]], float(fb["mean"]),
+                                 float(fb["std"]))
+    model, _ = _model(seed, tag, 0)
+    ctx = lib.get_context(0)
+    toks = g["tokens"]
+    for layer, name in [(-1, "emb"), (0, "layer0"), (5, "layer5"), (11, "layer11")]:
+        ctx.debug_tap(layer)
+        logits = model(feats).logits
+        h = ctx.debug_get_tap(4)
+        ref_tok, ref_norm = g[f"{tag}_{name}_tok"], g[f"{tag}_{name}_norm"]
+        scale = np.abs(ref_tok).max()
+        assert np.abs(h[:, toks] - ref_tok).max() <= 2e-4 * scale, name
+        assert np.abs(np.linalg.norm(h, axis=-1) - ref_norm).max() <= 2e-4 * ref_norm.max(), name
+    ctx.debug_tap(-2)
+    err = np.abs(logits - g[f"{tag}_logits"]).max()
+    print(f"[{tag}] f16x3 max-abs logit err vs transformers fp32: {err:.3e}")
+    assert err <= TOL
+    # torch tensor in -> torch tensor out (model(feats).logits contract)
+    import torch
+    lt = model(torch.from_numpy(feats)).logits
+    assert tuple(lt.shape) == (4, 2) and lt.dtype == torch.float32
+    assert np.array_equal(lt.numpy(), logits)
+    # single-pass fp16: faster, error stated (not the parity mode)
+    model.set_compute_mode("f16")
+    err1 = np.abs(model(feats).logits - g[f"{tag}_logits"]).max()
+    print(f"[{tag}] f16   max-abs logit err vs transformers fp32: {err1:.3e}")
+    assert err1 <= 2e-2
+
+
+def test_v4_key_scheme_loads_identically(G):
+    from zkast import ZkASTConfig, ZkASTForAudioClassification, synth
+    sd = synth.make_ast_weights(12, "init")
+    ren = {"attention.q_proj": "attention.attention.query", "attention.k_proj": "attention.attention.key",
+           "attention.v_proj": "attention.attention.value", "attention.o_proj": "attention.output.dense",
+           "mlp.fc1": "intermediate.dense", "mlp.fc2": "output.dense"}
+    sd4 = {}
+    for k, v in sd.items():
+        if ".layers." in k:
+            k = k.replace(".layers.", ".encoder.layer.")
+            for a, b in ren.items():
+                k = k.replace(a, b)
+        sd4[k] = v
+    fb = G["fbank"]
+    feats = orc.extract_features(synth.golden_windows()[[0, 1, 2, 4]], float(fb["mean"]), float(fb["std"]))
+    m4 = ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd4, stage=1)
+    l4 = m4(feats).logits
+    assert np.abs(l4 - G["model"]["init_logits"]).max() <= TOL
+    with pytest.raises(Exception, match="missing tensor"):
+        bad = dict(sd)
+        bad.pop("classifier.dense.weight")
+        ZkASTForAudioClassification(ZkASTConfig(num_labels=2), bad, stage=1)
+
+
+def test_forward_probs_and_cascade_vs_reference_run(G):
+    """tests/golden/cascade.npz holds the output of the REFERENCE's forward_probs on 16 windows (ragged batches of 5)."""
+    from zkast import ZkASTFeatureExtractor, classify_recording, forward_probs, synth
+    c = G["cascade"]
+    w16 = synth.synth_windows(int(c["audio_seed"]), 16)
+    m1, sd1 = _model(int(c["s1_seed"]), "wide", 0, shift=float(c["s1_bias_shift"]))
+    m2, sd2 = _model(int(c["s2_seed"]), "wide", 1, shift=float(c["s2_bias_shift"]), mean=float(c["s2_mean"]),
+                     std=float(c["s2_std"]))
+    fx1 = ZkASTFeatureExtractor(mean=float(c["s1_mean"]), std=float(c["s1_std"]))
+    fx2 = ZkASTFeatureExtractor(mean=float(c["s2_mean"]), std=float(c["s2_std"]))
+    p1 = forward_probs(m1, fx1, list(w16), 5)
+    assert p1.shape == (16, 2) and p1.dtype == np.float32
+    assert np.abs(p1 - c["s1_probs"]).max() <= 3e-4
+    assert np.allclose(p1.sum(1), 1.0, atol=1e-6)
+    p2 = forward_probs(m2, fx2, list(w16), 16)
+    assert np.abs(p2 - c["s2_probs_all"]).max() <= 3e-4
+    assert forward_probs(m1, fx1, [], 5).shape == (0,)
+    # fused cascade on the recording the 16 windows were cut from
+    rec = synth.synth_recording(int(c["audio_seed"]), 16000 + 15 * 8000)
+    for thr1, thr2, mp in [(0.5, 0.5, None), (0.55, 0.4, None), (0.5, 0.5, 0.52)]:
+        summ, s1p, s1_preds, cls2, res2 = classify_recording(rec, m1, fx1, m2, fx2, 1.0, 0.5, thr1, thr2, mp)
+        ref_idx = orc.stage1_gate(c["s1_probs"], np.float32(thr1), None if mp is None else np.float32(mp))
+        assert [i for i, _ in res2] == ref_idx.tolist()
+        ref_res = [(int(i), c["s2_probs_all"][i]) for i in ref_idx]
+        ref_sum = orc.summarize_stage_outputs(c["s1_probs"], ref_res, thr2)
+        for k, v in ref_sum.items():
+            if isinstance(v, (int, type(None))):
+                assert summ[k] == v, k
+            else:
+                assert np.allclose(summ[k], v, atol=3e-4), k
+        assert np.abs(s1p - c["s1_probs"]).max() <= 3e-4
+        for (i, pr) in res2:
+            assert np.abs(pr - c["s2_probs_all"][i]).max() <= 3e-4
+
+
+def test_batch_properties_at_full_size():
+    """size-independent properties at BASELINE config-2 scale (B=256): per-window independence (permutation and
+    micro-batch invariance are bit-exact: no cross-window arithmetic anywhere), logits finite, softmax rows sum to 1."""
+    from zkast import lib, synth
+    model, sd = _model(31, "wide", 0)
+    ctx = lib.get_context(0)
+    B = 256
+    rec = synth.synth_recording(17, 16000 + (B - 1) * 8000)
+    ctx.logmel(rec, rec.size, 0, 8000, 16000, B)
+    ctx.set_micro_batch(64)
+    l_a = model.forward_from_slot(B)
+    assert np.isfinite(l_a).all()
+    perm = np.random.default_rng(0).permutation(B).astype(np.int32)
+    l_p = model.forward_from_slot(B, perm)
+    assert np.array_equal(l_p, l_a[perm])
+    ctx.set_micro_batch(24)   # ragged last micro-batch (256 = 10*24 + 16)
+    l_b = model.forward_from_slot(B)
+    ctx.set_micro_batch(64)
+    assert np.array_equal(l_a, l_b)
+    p = ctx.softmax(l_a)
+    assert np.allclose(p.sum(1), 1.0, atol=1e-6)
+    # spot-check 3 of the 256 windows against the CPU oracle
+    W = orc.ASTWeights(sd)
+    wins = orc.window_audio(rec)
+    pick = [0, 101, 255]
+    feats = orc.extract_features([wins[i] for i in pick], -1.1509622, 3.5340312)
+    ref = orc.ast_forward(feats, W)
+    assert np.abs(l_a[pick] - ref).max() <= TOL

@@ -1,0 +1,363 @@
+"""Host-side mirror of the reference's two-stage long-audio script, function for function
+(src/test_long_audio_windows_2stage.py and the options the cached variant adds,
+src/test_long_audio_windows_2stage_cache.py): same names, argument meaning, return types and JSON schema, with the
+feature extraction, both AST forwards, the softmax and the gate running as HIP kernels behind libzkast.so.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import struct
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import lib as _lib
+from .feature_extraction import ZkASTFeatureExtractor
+from .modeling import ZkASTConfig, ZkASTForAudioClassification
+
+SAMPLING_RATE = 16000
+
+
+# ----------------- Audio helpers -----------------
+def read_wav(path: str) -> Tuple[np.ndarray, int]:
+    """Minimal RIFF/WAVE reader (PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE) ->
+    (channels, frames) float32 in [-1, 1], sample rate.  Stands in for torchaudio.load
+    (src/test_long_audio_windows_2stage.py:54); the files it reads are written by utils/PrepareDatasetLongAudio.py:59-67
+    (soundfile, mono PCM_16, native rate)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, raw = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            tag, ch, sr, _br, _ba, bits = struct.unpack("<HHIIHH", body[:16])
+            if tag == 0xFFFE and len(body) >= 26:
+                tag = struct.unpack("<H", body[24:26])[0]
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            raw = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or raw is None:
+        raise ValueError(f"{path}: missing fmt/data chunk")
+    tag, ch, sr, bits = fmt
+    if tag == 1:
+        if bits == 16:
+            x = np.frombuffer(raw, "<i2").astype(np.float32) / 32768.0
+        elif bits == 8:
+            x = (np.frombuffer(raw, np.uint8).astype(np.float32) - 128.0) / 128.0
+        elif bits == 24:
+            b = np.frombuffer(raw[: len(raw) // 3 * 3], np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            v = np.where(v >= 1 << 23, v - (1 << 24), v)
+            x = v.astype(np.float32) / float(1 << 23)
+        elif bits == 32:
+            x = (np.frombuffer(raw, "<i4").astype(np.float64) / float(1 << 31)).astype(np.float32)
+        else:
+            raise ValueError(f"{path}: unsupported PCM width {bits}")
+    elif tag == 3:
+        x = np.frombuffer(raw, "<f4" if bits == 32 else "<f8").astype(np.float32)
+    else:
+        raise ValueError(f"{path}: unsupported WAVE format tag {tag}")
+    n = x.shape[0] // ch
+    return np.ascontiguousarray(x[: n * ch].reshape(n, ch).T), sr
+
+
+def write_wav_pcm16(path: str, audio: np.ndarray, sr: int):
+    a = np.clip(np.asarray(audio, dtype=np.float64), -1.0, 1.0 - 1.0 / 32768)
+    pcm = np.round(a * 32768.0).astype("<i2").tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " +
+                struct.pack("<IHHIIHH", 16, 1, 1, sr, sr * 2, 2, 16) + b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+
+def load_audio(path: str, target_sr: int = SAMPLING_RATE, device: int = 0) -> np.ndarray:
+    """src/test_long_audio_windows_2stage.py:53-59: load, mean over channels, resample to 16 kHz (on the GPU)."""
+    wav, sr = read_wav(path)
+    if wav.shape[0] > 1:
+        wav = wav.mean(axis=0, keepdims=True)
+    x = np.ascontiguousarray(wav[0], dtype=np.float32)
+    if sr != target_sr:
+        x = _lib.get_context(device).resample(x, sr, target_sr)
+    return x
+
+
+def window_geometry(n_samples: int, window_sec: float, hop_sec: float, sr: int = SAMPLING_RATE):
+    """(n_windows, win, hop) of window_audio (:62-75): starts range(0, max(1, T-win+1), hop)."""
+    win = int(window_sec * sr)
+    hop = int(hop_sec * sr)
+    if win <= 0 or hop <= 0:
+        raise ValueError("window-sec and hop-sec must be > 0")
+    return len(range(0, max(1, n_samples - win + 1), hop)), win, hop
+
+
+def window_audio(audio: np.ndarray, window_sec: float, hop_sec: float, sr: int = SAMPLING_RATE) -> List[np.ndarray]:
+    win = int(window_sec * sr)
+    hop = int(hop_sec * sr)
+    out = []
+    for start in range(0, max(1, len(audio) - win + 1), hop):
+        segment = audio[start:start + win]
+        if len(segment) < win:
+            pad = np.zeros(win, dtype=audio.dtype)
+            pad[: len(segment)] = segment
+            segment = pad
+        out.append(segment)
+    return out
+
+
+def batch_iter(items, batch_size: int):
+    for i in range(0, len(items), batch_size):
+        yield items[i:i + batch_size]
+
+
+# ----------------- Model loading -----------------
+def load_stage_model(model_root: str, label_order: List[str], stage: int = 0, compute_mode="f16x3", device: int = 0):
+    """:86-98.  `stage` picks the library weight slot (0 for the Idle/Swallow model, 1 for Healthy/Zenker)."""
+    fx = ZkASTFeatureExtractor.from_pretrained(model_root, device=device)
+    config = ZkASTConfig.from_pretrained(model_root)
+    label2id = {lbl: i for i, lbl in enumerate(label_order)}
+    config.label2id = label2id
+    config.id2label = {v: k for k, v in label2id.items()}
+    model = ZkASTForAudioClassification.from_pretrained(model_root, config=config, stage=stage,
+                                                        compute_mode=compute_mode, device=device)
+    model.eval()
+    model.bind_feature_extractor(fx)
+    return fx, model
+
+
+# ----------------- Inference -----------------
+def forward_probs(model, fx, windows: List[np.ndarray], batch_size: int) -> np.ndarray:
+    """:104-113, same contract: list of 1-D float32 windows -> (N, 2) float32 softmax probabilities; an empty list
+    gives np.zeros((0,)).  Written against the drop-in objects exactly like the original loop."""
+    probs_all = []
+    ctx = _lib.get_context(getattr(model, "_device", 0))
+    for batch in batch_iter(windows, batch_size):
+        inputs = fx(batch, sampling_rate=SAMPLING_RATE, return_tensors="np")
+        feats = inputs[fx.model_input_names[0]]
+        logits = model(feats).logits
+        probs_all.append(ctx.softmax(np.asarray(logits)))
+    return np.concatenate(probs_all, axis=0) if probs_all else np.zeros((0,))
+
+
+def forward_probs_recording(model, fx, audio: np.ndarray, window_sec: float, hop_sec: float,
+                            win_idx=None) -> np.ndarray:
+    """Fused equivalent of forward_probs(model, fx, window_audio(audio, ...)): the windows are never materialised,
+    the log-mel stays on the device, and the (B,1024,128) tensor is never built."""
+    n, win, hop = window_geometry(len(audio), window_sec, hop_sec)
+    ctx = model._ctx
+    model.bind_feature_extractor(fx)
+    ctx.logmel(np.ascontiguousarray(audio, dtype=np.float32), len(audio), 0, hop, win, n)
+    logits = model.forward_from_slot(n, win_idx)
+    return ctx.softmax(logits) if logits.shape[0] else np.zeros((0,))
+
+
+# ----------------- File discovery -----------------
+def _wav_num_frames(path: str) -> int:
+    try:
+        wav, _ = read_wav(path)
+        return wav.shape[1]
+    except Exception:
+        return 0
+
+
+def discover_two_files(root: str, patient_id: str, pattern: str) -> List[str]:
+    """:119-142."""
+    base = os.path.abspath(root)
+    matches = []
+    for dirpath, _, filenames in os.walk(base):
+        if patient_id not in dirpath:
+            continue
+        for fn in filenames:
+            if glob.fnmatch.fnmatch(fn, pattern):
+                matches.append(os.path.join(dirpath, fn))
+    matches = sorted(matches)
+    if len(matches) > 2:
+        lengths = [(p, _wav_num_frames(p)) for p in matches]
+        matches = [p for p, _ in sorted(lengths, key=lambda x: x[1], reverse=True)[:2]]
+    if len(matches) != 2:
+        raise ValueError(f"Expected exactly 2 files for patient {patient_id}, found {len(matches)}: {matches}")
+    return matches
+
+
+# ----------------- Aggregation -----------------
+def summarize_stage_outputs(stage1_probs: np.ndarray, stage2_probs_or_none: List[Tuple[int, np.ndarray]],
+                            stage1_label_order: List[str], stage2_label_order: List[str],
+                            stage2_threshold: float = 0.5, use_argmax: bool = False) -> Dict[str, Any]:
+    """:148-195 (and ..._cache.py:243-297 for use_argmax), including the reference's quirk that the stage-1 counts
+    are recomputed by plain argmax, ignoring --stage1-threshold."""
+    stage1_preds = stage1_probs.argmax(axis=1)
+    stage2_aligned = [None] * len(stage1_preds)
+    for idx, probs in stage2_probs_or_none:
+        stage2_aligned[idx] = probs
+    idle_count = int((stage1_preds == 0).sum())
+    swallow_count = int((stage1_preds == 1).sum())
+    evaluated = [p for p in stage2_aligned if p is not None]
+    if use_argmax:
+        healthy_count = int(sum(1 for p in evaluated if np.argmax(p) == 0))
+        zenker_count = int(sum(1 for p in evaluated if np.argmax(p) == 1))
+    else:
+        healthy_count = int(sum(1 for p in evaluated if p[1] < stage2_threshold))
+        zenker_count = int(sum(1 for p in evaluated if p[1] >= stage2_threshold))
+    n = len(stage1_preds)
+    return {
+        "num_windows": int(n),
+        "stage1_idle_windows": idle_count,
+        "stage1_swallow_windows": swallow_count,
+        "stage1_swallow_ratio": (swallow_count / n) if n else 0.0,
+        "stage1_mean_probs": stage1_probs.mean(axis=0).tolist() if len(stage1_probs) else None,
+        "stage2_mean_probs_over_swallow": np.mean(evaluated, axis=0).tolist() if swallow_count else None,
+        "stage2_swallow_windows_evaluated": int(len(evaluated)),
+        "stage2_healthy_windows": healthy_count,
+        "stage2_zenker_windows": zenker_count,
+        "stage2_zenker_ratio_over_swallow": (zenker_count / swallow_count) if swallow_count else None,
+    }
+
+
+def classify_recording(audio: np.ndarray, model_s1, fx_s1, model_s2, fx_s2, window_sec: float = 1.0,
+                       hop_sec: float = 0.5, stage1_threshold: float = 0.5, stage2_threshold: float = 0.5,
+                       stage1_forward_min_prob: Optional[float] = None, stage2_argmax: bool = False,
+                       stage1_label_order=("Idle", "Swallow"), stage2_label_order=("Healthy", "Zenker")):
+    """The per-file body of main() (:301-348) as ONE library call (zk_two_stage): log-mel once, stage-1 forward,
+    on-device gate + compaction, stage-2 forward on the gated windows re-normalised with stage 2's mean/std.
+    Returns (summary dict, s1_probs, s1_preds, stage2_aligned_classes, stage2_results)."""
+    ctx = model_s1._ctx
+    n, win, hop = window_geometry(len(audio), window_sec, hop_sec)
+    model_s1.bind_feature_extractor(fx_s1)
+    model_s2.bind_feature_extractor(fx_s2)
+    s1_logits, swallow_indices, s2_logits = ctx.two_stage(
+        np.ascontiguousarray(audio, dtype=np.float32), len(audio), 0, hop, win, n, np.float32(stage1_threshold),
+        stage1_forward_min_prob)
+    s1_probs = ctx.softmax(s1_logits)
+    if s1_probs.ndim != 2 or s1_probs.shape[1] != 2:
+        raise RuntimeError("Stage1 output shape unexpected; expected (N,2)")
+    p_swallow = s1_probs[:, 1]
+    s1_preds = s1_probs.argmax(axis=1)
+    s1_preds = np.where((s1_preds == 1) & (p_swallow >= stage1_threshold), 1, 0)
+    s2_probs = ctx.softmax(s2_logits) if len(swallow_indices) else np.zeros((0, 2), np.float32)
+    stage2_results = [(int(g), s2_probs[i]) for i, g in enumerate(swallow_indices)]
+    stage2_aligned_classes = np.full(len(s1_preds), -1, dtype=int)
+    for gidx, probs in stage2_results:
+        if stage2_argmax:
+            stage2_aligned_classes[gidx] = int(np.argmax(probs))
+        else:
+            stage2_aligned_classes[gidx] = 1 if probs[1] >= stage2_threshold else 0
+    summary = summarize_stage_outputs(s1_probs, stage2_results, list(stage1_label_order), list(stage2_label_order),
+                                      stage2_threshold, stage2_argmax)
+    return summary, s1_probs, s1_preds, stage2_aligned_classes, stage2_results
+
+
+def aggregate_files(per_file: Dict[str, Dict[str, Any]], files: List[str]) -> Dict[str, Any]:
+    """:360-382."""
+    vals = list(per_file.values())
+    total_windows = int(sum(f["num_windows"] for f in vals))
+    total_swallow = sum(f["stage1_swallow_windows"] for f in vals)
+    total_zenker = sum(f["stage2_zenker_windows"] for f in vals)
+    return {
+        "files_used": files,
+        "total_windows": total_windows,
+        "total_idle_windows": int(sum(f["stage1_idle_windows"] for f in vals)),
+        "total_swallow_windows": int(total_swallow),
+        "total_swallow_ratio": (total_swallow / max(1, total_windows)),
+        "total_swallow_windows_evaluated_stage2": int(sum(f["stage2_swallow_windows_evaluated"] for f in vals)),
+        "total_healthy_windows": int(sum(f["stage2_healthy_windows"] for f in vals)),
+        "total_zenker_windows": int(total_zenker),
+        "overall_zenker_ratio_over_swallow": (total_zenker / total_swallow) if total_swallow else None,
+    }
+
+
+def run_patient(files: List[str], model_s1, fx_s1, model_s2, fx_s2, args_like: Dict[str, Any],
+                audios: Optional[List[np.ndarray]] = None) -> Dict[str, Any]:
+    """The `output` dict main() writes as <pid>_2stage.json (:384-396), for two files (or in-memory recordings)."""
+    per_file = {}
+    for idx, path in enumerate(files):
+        audio = audios[idx] if audios is not None else load_audio(path)
+        summary, *_ = classify_recording(
+            audio, model_s1, fx_s1, model_s2, fx_s2, args_like.get("window_sec", 1.0), args_like.get("hop_sec", 0.5),
+            args_like.get("stage1_threshold", 0.5), args_like.get("stage2_threshold", 0.5),
+            args_like.get("stage1_forward_min_prob"), args_like.get("stage2_argmax", False))
+        per_file[f"file_{idx}"] = {"path": path, **summary}
+    return {
+        "config": {
+            "stage1_model_root": args_like.get("stage1_model_root"),
+            "stage2_model_root": args_like.get("stage2_model_root"),
+            "window_sec": args_like.get("window_sec", 1.0),
+            "hop_sec": args_like.get("hop_sec", 0.5),
+            "batch_size": args_like.get("batch_size", 128),
+            "stage1_threshold": args_like.get("stage1_threshold", 0.5),
+            "files": files,
+        },
+        "per_file": per_file,
+        "aggregate": aggregate_files(per_file, files),
+    }
+
+
+# ----------------- CLI (same flags as the reference parser, :201-248, plus the cached variant's two) -------------
+def build_arg_parser():
+    ap = argparse.ArgumentParser(description="Two-stage AST inference over two long audio files (windowed), MI355X.")
+    ap.add_argument("--stage1-model-root")
+    ap.add_argument("--stage2-model-root")
+    ap.add_argument("--fold", type=int)
+    ap.add_argument("--file-a")
+    ap.add_argument("--file-b")
+    ap.add_argument("--patient-id")
+    ap.add_argument("--long-audio-root")
+    ap.add_argument("--pattern", default="*.wav")
+    ap.add_argument("--window-sec", type=float, default=1.0)
+    ap.add_argument("--hop-sec", type=float, default=0.5)
+    ap.add_argument("--batch-size", type=int, default=128)
+    ap.add_argument("--stage1-threshold", type=float, default=0.5)
+    ap.add_argument("--stage2-threshold", type=float, default=0.5)
+    ap.add_argument("--stage1-forward-min-prob", type=float, default=None)
+    ap.add_argument("--stage2-argmax", action="store_true")
+    ap.add_argument("--output-json")
+    ap.add_argument("--show-first-n", type=int, default=5)
+    ap.add_argument("--compute-mode", default="f16x3", choices=["f16", "f16x3"])
+    return ap
+
+
+def main(argv=None):
+    args = build_arg_parser().parse_args(argv)
+    if args.file_a and args.file_b:
+        files = [args.file_a, args.file_b]
+    else:
+        if not (args.patient_id and args.long_audio_root):
+            raise ValueError("Provide either --file-a & --file-b or (--patient-id and --long-audio-root).")
+        files = discover_two_files(args.long_audio_root, args.patient_id, args.pattern)
+    print(f"Using files:\n  A: {files[0]}\n  B: {files[1]}")
+    if args.fold is not None:
+        project_root = os.getcwd()
+        if not args.stage1_model_root:
+            args.stage1_model_root = os.path.join(project_root, "runs", "ast_classifier_stage1", f"fold{args.fold}", "best")
+        if not args.stage2_model_root:
+            args.stage2_model_root = os.path.join(project_root, "runs", "ast_classifier_stage2", f"fold{args.fold}", "best")
+    if not (args.stage1_model_root and args.stage2_model_root):
+        raise ValueError("Model roots must be provided either explicitly or via --fold.")
+    if args.window_sec <= 0 or args.hop_sec <= 0:
+        raise ValueError("window-sec and hop-sec must be > 0")
+    if args.hop_sec > args.window_sec:
+        print("[WARN] hop-sec larger than window-sec; windows will be disjoint with gaps.")
+    fx_s1, model_s1 = load_stage_model(args.stage1_model_root, ["Idle", "Swallow"], 0, args.compute_mode)
+    fx_s2, model_s2 = load_stage_model(args.stage2_model_root, ["Healthy", "Zenker"], 1, args.compute_mode)
+    output = run_patient(files, model_s1, fx_s1, model_s2, fx_s2, vars(args))
+    for k, v in output["per_file"].items():
+        print(f"{k}: {v['num_windows']} windows, swallow {v['stage1_swallow_windows']}, zenker {v['stage2_zenker_windows']}")
+    if not args.output_json and args.patient_id:
+        os.makedirs("outputs", exist_ok=True)
+        args.output_json = os.path.join("outputs", f"{args.patient_id}_2stage.json")
+    if args.output_json:
+        out_dir = os.path.dirname(args.output_json)
+        if out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+        with open(args.output_json, "w") as f:
+            json.dump(output, f, indent=2)
+        print(f"Saved JSON: {args.output_json}")
+    return output
+
+
+if __name__ == "__main__":
+    main()
