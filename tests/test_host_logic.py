@@ -1,0 +1,147 @@
+"""CPU: host-side mirror of the reference script (no GPU calls): window geometry, summaries, aggregation, JSON
+schema, WAV reader, config / preprocessor parsing, sharding arithmetic."""
+import json
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+from oracle import ast_oracle as orc
+from zkast import dist as zdist
+from zkast import pipeline as pl
+from zkast.feature_extraction import ZkASTFeatureExtractor
+from zkast.modeling import ZkASTConfig
+
+
+@pytest.fixture(scope="module")
+def cases(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "cascade_cases.json")))
+
+
+def test_window_audio_matches_reference_counts(golden_dir):
+    exp = json.load(open(os.path.join(golden_dir, "windows.json")))
+    for key, e in exp.items():
+        if not key.isdigit():
+            continue
+        T = int(key)
+        n, win, hop = pl.window_geometry(T, 1.0, 0.5)
+        assert (n, win, hop) == (e["n"], 16000, 8000)
+        if T <= 40000:
+            a = np.arange(T, dtype=np.float32)
+            wins = pl.window_audio(a, 1.0, 0.5)
+            assert len(wins) == e["n"] and all(len(w) == 16000 for w in wins)
+    with pytest.raises(ValueError):
+        pl.window_geometry(16000, 0.0, 0.5)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 200000), st.sampled_from([0.25, 0.5, 1.0, 2.0]), st.sampled_from([0.1, 0.25, 0.5, 1.0, 1.5]))
+def test_window_geometry_property(T, w, h):
+    n, win, hop = pl.window_geometry(T, w, h)
+    assert n == len(orc.window_audio(np.zeros(T, np.float32), w, h))
+    assert n >= 1 and (T < win or (n - 1) * hop + win <= T)
+
+
+def test_summaries_match_reference_cases(cases):
+    for name, c in cases["cases"].items():
+        s1 = np.asarray(c["s1"], np.float32)
+        s2 = np.asarray(c["s2_all"], np.float32)
+        idx = zdist.gate_indices(s1, c["thr1"], c["min_prob"])
+        assert idx.tolist() == c["swallow_idx"], name
+        res = [(int(i), s2[i]) for i in idx]
+        summ = pl.summarize_stage_outputs(s1, res, ["Idle", "Swallow"], ["Healthy", "Zenker"], c["thr2"],
+                                          c["use_argmax"])
+        assert json.loads(json.dumps(summ)) == pytest.approx(c["summary"], nan_ok=True, abs=1e-7), name
+
+
+def test_aggregate_and_schema(cases):
+    c = cases["cases"]["thr_0p5"]
+    per_file = {"file_0": {"path": "a.wav", **c["summary"]}, "file_1": {"path": "b.wav", **c["summary"]}}
+    agg = pl.aggregate_files(per_file, ["a.wav", "b.wav"])
+    assert agg["total_windows"] == 2 * c["summary"]["num_windows"]
+    assert agg["total_swallow_windows"] == 2 * c["summary"]["stage1_swallow_windows"]
+    assert agg["overall_zenker_ratio_over_swallow"] == pytest.approx(
+        c["summary"]["stage2_zenker_windows"] / c["summary"]["stage1_swallow_windows"])
+    assert set(agg) == {"files_used", "total_windows", "total_idle_windows", "total_swallow_windows",
+                        "total_swallow_ratio", "total_swallow_windows_evaluated_stage2", "total_healthy_windows",
+                        "total_zenker_windows", "overall_zenker_ratio_over_swallow"}
+    none = cases["cases"]["no_swallow"]["summary"]
+    agg0 = pl.aggregate_files({"file_0": none, "file_1": none}, ["a", "b"])
+    assert agg0["overall_zenker_ratio_over_swallow"] is None and agg0["total_swallow_ratio"] == 0.0
+
+
+def test_wav_roundtrip_and_formats(tmp_path):
+    import struct
+    rng = np.random.default_rng(0)
+    x = (0.5 * rng.uniform(-1, 1, 4800)).astype(np.float32)
+    p = str(tmp_path / "a.wav")
+    pl.write_wav_pcm16(p, x, 48000)
+    wav, sr = pl.read_wav(p)
+    assert sr == 48000 and wav.shape == (1, 4800) and np.abs(wav[0] - x).max() <= 1.0 / 32768
+    # stereo float32 with an odd-sized LIST chunk before data
+    st2 = np.stack([x, -x], 1).astype("<f4").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 0) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 3, 2, 16000, 128000, 8, 32)
+    junk = b"LIST" + struct.pack("<I", 3) + b"abc" + b"\0"
+    p2 = str(tmp_path / "b.wav")
+    open(p2, "wb").write(hdr + junk + b"data" + struct.pack("<I", len(st2)) + st2)
+    wav, sr = pl.read_wav(p2)
+    assert sr == 16000 and wav.shape == (2, 4800) and np.array_equal(wav[0], x) and np.array_equal(wav[1], -x)
+    # 24-bit PCM
+    v = np.round(x * (1 << 23)).astype(np.int32)
+    b24 = b"".join(int(i & 0xFFFFFF).to_bytes(3, "little") for i in v)
+    hdr = b"RIFF" + struct.pack("<I", 0) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, 8000, 24000, 3, 24)
+    p3 = str(tmp_path / "c.wav")
+    open(p3, "wb").write(hdr + b"data" + struct.pack("<I", len(b24)) + b24)
+    wav, sr = pl.read_wav(p3)
+    assert sr == 8000 and np.abs(wav[0] - x).max() <= 2.0 ** -23
+    with pytest.raises(ValueError):
+        open(p3, "wb").write(b"nope")
+        pl.read_wav(p3)
+
+
+def test_discover_two_files(tmp_path):
+    d = tmp_path / "Long" / "Zenker" / "006"
+    d.mkdir(parents=True)
+    for name, n in [("a.wav", 100), ("b.wav", 300), ("c.wav", 200)]:
+        pl.write_wav_pcm16(str(d / name), np.zeros(n, np.float32), 16000)
+    got = pl.discover_two_files(str(tmp_path), "006", "*.wav")
+    assert [os.path.basename(p) for p in got] == ["b.wav", "c.wav"]      # the two longest
+    with pytest.raises(ValueError, match="Expected exactly 2 files"):
+        pl.discover_two_files(str(tmp_path), "007", "*.wav")
+
+
+def test_feature_extractor_config_contract(tmp_path):
+    fx = ZkASTFeatureExtractor(mean=-1.15, std=3.5)
+    d = fx.to_dict()
+    json.dumps(d)
+    assert d["mean"] == -1.15 and d["std"] == 3.5 and d["num_mel_bins"] == 128 and d["max_length"] == 1024
+    fx.save_pretrained(str(tmp_path))
+    fx2 = ZkASTFeatureExtractor.from_pretrained(str(tmp_path))
+    assert fx2.to_dict() == d and fx.model_input_names[0] == "input_values"
+    assert ZkASTFeatureExtractor(mean=0.0, std=1.0).to_dict() != d
+    with pytest.raises(ValueError, match="sampling rate"):
+        fx._check_rate(8000)
+    with pytest.raises(OSError):
+        ZkASTFeatureExtractor.from_pretrained(str(tmp_path / "missing"))
+
+
+def test_config_parsing(tmp_path):
+    cfg = {"hidden_size": 768, "num_hidden_layers": 12, "id2label": {"0": "Idle", "1": "Swallow"},
+           "label2id": {"Idle": 0, "Swallow": 1}, "architectures": ["ASTForAudioClassification"], "torch_dtype": "float32"}
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    c = ZkASTConfig.from_pretrained(str(tmp_path))
+    assert c.num_labels == 2 and c.id2label == {0: "Idle", 1: "Swallow"} and c.layer_norm_eps == 1e-12
+    with pytest.raises(ValueError):
+        ZkASTConfig(hidden_act="relu")
+
+
+@settings(max_examples=50, deadline=None)
+@given(st.integers(0, 5000), st.integers(1, 8))
+def test_shard_ranges_partition(n, world):
+    spans = [zdist.shard_range(n, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    sizes = [hi - lo for lo, hi in spans]
+    assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,137 @@
+"""CPU: the oracle (oracle/ast_oracle.py) against EVERY golden fixture in tests/golden/ — the fixtures were produced
+by the real transformers classes and the reference module's own functions (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ast_oracle as orc
+from zkast import synth
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return {
+        "windows": json.load(open(os.path.join(golden_dir, "windows.json"))),
+        "fbank": np.load(os.path.join(golden_dir, "fbank.npz")),
+        "model": np.load(os.path.join(golden_dir, "model.npz")),
+        "cascade": np.load(os.path.join(golden_dir, "cascade.npz")),
+        "cases": json.load(open(os.path.join(golden_dir, "cascade_cases.json"))),
+    }
+
+
+def test_window_indexing(G):
+    for key, exp in G["windows"].items():
+        if not key.isdigit():
+            continue
+        T = int(key)
+        audio = np.zeros(T, dtype=np.float32)
+        audio[: min(T, 100)] = 1.0
+        wins = orc.window_audio(audio, 1.0, 0.5)
+        assert len(wins) == exp["n"]
+        assert sorted({len(w) for w in wins}) == exp["lens"]
+        assert float(wins[0].sum()) == exp["first_sum"] and float(wins[-1].sum()) == exp["last_sum"]
+    assert len(orc.window_audio(np.zeros(80000, np.float32), 1.0, 1.5)) == G["windows"]["hop_gt_win"]["n"]
+    assert len(orc.window_audio(np.zeros(16000, np.float32), 0.25, 0.1)) == G["windows"]["win_0p25_hop_0p1"]["n"]
+
+
+def test_fbank_bit_exact(G):
+    fb = G["fbank"]
+    assert np.array_equal(orc.mel_filter_bank_kaldi(), fb["mel_filters"])
+    assert np.abs(orc.hann_window() - fb["window"]).max() < 1e-15
+    wins = synth.golden_windows()
+    raw = orc.extract_features(wins, 0.0, 1.0, do_normalize=False)
+    assert np.array_equal(raw[:, :98], fb["raw_rows"])
+    assert np.all(raw[:, 98:] == 0.0)
+    nrm = orc.extract_features(wins, float(fb["mean"]), float(fb["std"]))
+    assert np.array_equal(nrm[:, :98], fb["norm_rows"])
+    assert np.all(nrm[:, 98:] == fb["norm_pad_value"])
+    short = orc.extract_features([wins[0][:4000]], 0.0, 1.0, False)[0]
+    assert int((np.abs(short).sum(1) != 0).sum()) == int(fb["short_n"])
+    assert np.array_equal(short[:30], fb["short_rows"])
+    long2 = orc.extract_features([np.concatenate([wins[0], wins[2]])], 0.0, 1.0, False)[0]
+    assert int((np.abs(long2).sum(1) != 0).sum()) == int(fb["long_n"])
+    assert np.array_equal(long2[:198:9], fb["long_rows"])
+
+
+@pytest.mark.parametrize("tag,seed", [("wide", 11), ("init", 12)])
+def test_model_against_transformers(G, tag, seed):
+    g, fb = G["model"], G["fbank"]
+    feats = orc.extract_features(synth.golden_windows()[[0, 1]], float(fb["mean"]), float(fb["std"]))
+    sd = synth.make_ast_weights(seed, tag)
+    logits, hid = orc.ast_forward(feats, sd, return_hidden=True, chunk=2)
+    assert np.abs(logits - g[f"{tag}_logits"][:2]).max() <= 2e-5
+    assert np.abs(hid["pooled"] - g[f"{tag}_pooled"][:2]).max() <= 2e-5
+    toks = g["tokens"]
+    for name in ("emb", "layer0", "layer5", "layer11", "final_ln"):
+        ref_tok, ref_norm = g[f"{tag}_{name}_tok"][:2], g[f"{tag}_{name}_norm"][:2]
+        assert np.abs(hid[name][:, toks] - ref_tok).max() <= 3e-5 * max(1.0, np.abs(ref_tok).max()), name
+        assert np.abs(np.linalg.norm(hid[name], axis=-1) - ref_norm).max() <= 3e-5 * ref_norm.max(), name
+
+
+def test_v4_key_scheme(G):
+    sd = synth.make_ast_weights(12, "init", layers=[0])
+    W5 = orc.ASTWeights(sd)
+    ren = {"attention.q_proj": "attention.attention.query", "attention.k_proj": "attention.attention.key",
+           "attention.v_proj": "attention.attention.value", "attention.o_proj": "attention.output.dense",
+           "mlp.fc1": "intermediate.dense", "mlp.fc2": "output.dense"}
+    sd4 = {}
+    for k, v in sd.items():
+        if ".layers." in k:
+            k = k.replace(".layers.", ".encoder.layer.")
+            for a, b in ren.items():
+                k = k.replace(a, b)
+        sd4[k] = v
+    W4 = orc.ASTWeights(sd4)
+    assert W5.n_layers == 1 and W4.n_layers == 1 and not W4.v5
+    for k in W5.layer(0):
+        assert np.array_equal(W5.layer(0)[k][0], W4.layer(0)[k][0])
+
+
+def test_cascade_cases_match_reference_functions(G):
+    for name, c in G["cases"]["cases"].items():
+        s1 = np.asarray(c["s1"], dtype=np.float32)
+        s2 = np.asarray(c["s2_all"], dtype=np.float32)
+        idx = orc.stage1_gate(s1, c["thr1"], c["min_prob"])
+        assert idx.tolist() == c["swallow_idx"], name
+        res = [(int(i), s2[i]) for i in idx]
+        summ = orc.summarize_stage_outputs(s1, res, c["thr2"], c["use_argmax"])
+        ref = c["summary"]
+        assert set(summ) == set(ref), name
+        for k, v in ref.items():
+            if v is None:
+                assert summ[k] is None, (name, k)
+            elif isinstance(v, list):
+                if any(isinstance(x, float) and np.isnan(x) for x in v):
+                    assert all(np.isnan(x) for x in summ[k]), (name, k)
+                else:
+                    assert np.allclose(summ[k], v, atol=1e-7), (name, k)
+            elif isinstance(v, float) and np.isnan(v):
+                assert np.isnan(summ[k]), (name, k)
+            else:
+                assert summ[k] == pytest.approx(v, abs=1e-9), (name, k)
+
+
+def test_forward_probs_vs_reference_run_subset(G):
+    """2 of the 16 windows the reference's forward_probs was run on (12-layer model, CPU seconds)."""
+    c = G["cascade"]
+    w16 = synth.synth_windows(int(c["audio_seed"]), 16)
+    sd = synth.make_ast_weights(int(c["s1_seed"]), "wide")
+    sd["classifier.dense.bias"][1] += np.float32(c["s1_bias_shift"])
+    p = orc.forward_probs(sd, float(c["s1_mean"]), float(c["s1_std"]), list(w16[[0, 14]]), 2)
+    assert p.dtype == np.float32 and np.abs(p - c["s1_probs"][[0, 14]]).max() <= 1e-5
+    assert orc.forward_probs(sd, 0.0, 1.0, [], 4).shape == (0,)
+
+
+def test_resample_restatement_properties():
+    """parity unpinned (torchaudio absent): only self-consistency — length rule, DC gain, band-limited sine."""
+    x = np.ones(48000, np.float32)
+    y = orc.resample_sinc_hann(x, 48000, 16000)
+    assert y.shape[0] == 16000 and np.abs(y[100:-100] - 1.0).max() < 2e-3
+    t = np.arange(48000) / 48000.0
+    s = np.sin(2 * np.pi * 1000.0 * t).astype(np.float32)
+    y = orc.resample_sinc_hann(s, 48000, 16000)
+    ref = np.sin(2 * np.pi * 1000.0 * np.arange(16000) / 16000.0)
+    assert np.abs(y[200:-200] - ref[200:-200]).max() < 5e-3
+    assert orc.resample_sinc_hann(np.zeros(44101, np.float32), 44100, 16000).shape[0] == int(np.ceil(160 * 44101 / 441))
