@@ -4,16 +4,21 @@
 // ($TF/models/audio_spectrogram_transformer/modeling_audio_spectrogram_transformer.py:57-61,140-143,174,187-192).
 //
 // gfx950 design
-//  * 512-thread workgroup = 8 waves, one workgroup per CU (LDS-limited), v_mfma_f32_16x16x32_f16.
-//  * W is the MFMA "A" operand (rows = n) and X the "B" operand (cols = m): the accumulator then holds, per
-//    lane, 4 CONSECUTIVE n of one token row m, so epilogues store 8 B (fp16) / 16 B (fp32) per lane.
-//  * tiles are staged HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip); the LDS image is linear
-//    per wave-instruction, the 16-B chunk XOR swizzle f(row) = (row>>1)&(CPR-1) is applied to the SOURCE address
-//    and again on the ds_read_b128 side (conflict-free for the 16x16x32 operand pattern).
-//  * double-buffered LDS, one barrier per K tile.
-//  * NSPLIT=3: every operand is an (hi, lo) fp16 pair, acc += Wh·Xh + Wl·Xh + Wh·Xl  (fp32-equivalent product,
+//  * PERSISTENT: grid = min(#tiles, 256) workgroups of 512 threads (8 waves, one workgroup per CU); each workgroup
+//    walks its list of output tiles and treats (tile, k-step) as ONE stream, so the global->LDS prefetch ring keeps
+//    running across tile boundaries (no per-tile prologue bubble).  Tile order: consecutive groups of gridDim/8
+//    tiles (n fastest) go to one XCD, so the workgroups of an XCD share X row panels in its private L2.
+//  * W is the MFMA "A" operand (rows = n) and X the "B" operand (cols = m), v_mfma_f32_16x16x32_f16: a lane's 4
+//    accumulator registers are 4 CONSECUTIVE n of one token row m -> 8 B (fp16) / 16 B (fp32) stores.
+//  * tiles are staged HBM/L2 -> LDS with global_load_lds_dwordx4 into an NST-deep ring; the LDS image is linear per
+//    wave-instruction, the 16-B chunk XOR swizzle f(row) = (row>>1)&(CPR-1) is applied to the SOURCE address and
+//    again on the ds_read_b128 side (conflict-free for the 16x16x32 operand pattern, SQ_LDS_BANK_CONFLICT = 0).
+//  * one raw s_barrier per k-step behind a COUNTED s_waitcnt vmcnt((NST-2)*loads_per_step): NST-2 later k-steps stay
+//    in flight across the barrier (HBM/L2 latency under load is longer than one k-step of MFMAs).
+//  * the bias slice of a tile rides the same ring (one global_load_lds_dword per wave at k = 0) so the epilogue
+//    needs no VGPR-destination global load, which would make hipcc drain the ring with vmcnt(0).
+//  * NSPLIT=3: every operand is an (hi, lo) fp16 pair, acc += Wl·Xh + Wh·Xl + Wh·Xh  (fp32-equivalent product,
 //    2^-22 relative) — the mode that meets the 1e-3 logit tolerance; NSPLIT=1 is the plain fp16 pass.
-//  * blockIdx is remapped so that each XCD (private L2) works on a contiguous range of tiles that share X rows.
 #include "zk_common.h"
 
 namespace {
@@ -34,7 +39,12 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erf_v);
 }
 
-template <int NSPLIT, int BM, int BN, int BK, int WM, int WN, int EPI>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NSPLIT, int BM, int BN, int BK, int WM, int WN, int NST, int EPI>
 __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
   constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
   constexpr int ROWB = BK * 2;               // bytes per tile row
@@ -45,8 +55,16 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
   constexpr int KS = BK / 32;
   constexpr int XBYTES = BM * ROWB, WBYTES = BN * ROWB;
   constexpr int STAGE = NPL * (XBYTES + WBYTES);
+  constexpr int XI = BM / RPI / 8, WI = BN / RPI / 8;   // glds per wave per plane
+  constexpr int LPT = NPL * (XI + WI);                   // glds per wave per k-step
+  constexpr int INFLIGHT = (NST - 2) * LPT;              // allowed to stay in flight across the barrier
+  constexpr int BIAS_OFF = NST * STAGE;                  // 2 slots x 8 waves x 256 B
+  constexpr int SCR_OFF = BIAS_OFF + 2 * 8 * 256;         // epilogue transpose scratch, per wave 16 rows x 144 B
+  constexpr int SCR_STR = 144, SCR_WAVE = 16 * SCR_STR;
   static_assert(WM * WN == 8, "8 waves");
+  static_assert(TN == 64, "bias slot is one dword per lane");
   static_assert((BM / RPI) % 8 == 0 && (BN / RPI) % 8 == 0, "staging split over 8 waves");
+  static_assert(INFLIGHT < 64, "vmcnt field");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -55,53 +73,72 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  // ---- XCD-aware, bijective block remap (tn fastest inside an XCD's contiguous range) ----
   const int tiles_n = a.N / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
-  const int nwg = tiles_m * tiles_n;
-  int wg;
-  {
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tm = wg / tiles_n, tn = wg % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = a.K / BK;
+  // tile list of this workgroup: T(s) = (s*8 + xcd)*per + j   (blocks b and b+8 share an XCD: speed only)
+  const int per = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int first = xcd * per + jb;
+  const int stride = 8 * per;
+  const int my_tiles = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+  const int total = my_tiles * nk;
 
   const half_t* xp[2] = {a.x_hi, a.x_lo};
   const half_t* wp[2] = {a.w_hi, a.w_lo};
 
-  // ---- staging: per-lane source rows/chunks (constant over K) ----
+  // ---- staging: one k-step = LPT "pieces" (1-KiB global_load_lds_dwordx4 per wave), issued one per MFMA chunk ----
   const int srow = lane / CPR;               // row inside one wave-instruction
   const int schunk = lane % CPR;
-  auto stage = [&](int buf, int k0) {
-    char* base = smem + buf * STAGE;
-#pragma unroll
-    for (int p = 0; p < NPL; ++p) {
-#pragma unroll
-      for (int i = 0; i < BM / RPI / 8; ++i) {
-        const int instr = i * 8 + wave;
-        const int row = instr * RPI + srow;
-        int grow = m0 + row;
-        grow = grow < a.M ? grow : a.M - 1;
-        const int c = schunk ^ ((row >> 1) & (CPR - 1));
-        const half_t* src = xp[p] + (size_t)grow * a.K + k0 + c * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(base + p * XBYTES + instr * 1024),
-                                         16, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < BN / RPI / 8; ++i) {
-        const int instr = i * 8 + wave;
-        const int row = instr * RPI + srow;
-        const int c = schunk ^ ((row >> 1) & (CPR - 1));
-        const half_t* src = wp[p] + (size_t)(n0 + row) * a.K + k0 + c * 8;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)src,
-            (__attribute__((address_space(3))) void*)(base + NPL * XBYTES + p * WBYTES + instr * 1024), 16, 0, 0);
-      }
+  // load cursor (runs NST-1 steps ahead of the compute cursor)
+  int l_step = 0, l_k = 0, l_ord = 0, l_tile = first;
+  int l_m0 = (first / tiles_n) * BM, l_n0 = (first % tiles_n) * BN;
+  auto issue_piece = [&](int piece) {      // piece is a compile-time constant after unrolling
+    if (l_step >= total) return;
+    char* base = smem + (l_step % NST) * STAGE;
+    const int p = piece / (XI + WI), q = piece % (XI + WI);
+    const int k0 = l_k * BK;
+    if (q < XI) {
+      const int instr = q * 8 + wave;
+      const int row = instr * RPI + srow;
+      int grow = l_m0 + row;
+      grow = grow < a.M ? grow : a.M - 1;
+      const int c = schunk ^ ((row >> 1) & (CPR - 1));
+      const half_t* src = xp[p] + (size_t)grow * a.K + k0 + c * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + p * XBYTES + instr * 1024),
+                                       16, 0, 0);
+    } else {
+      const int instr = (q - XI) * 8 + wave;
+      const int row = instr * RPI + srow;
+      const int c = schunk ^ ((row >> 1) & (CPR - 1));
+      const half_t* src = wp[p] + (size_t)(l_n0 + row) * a.K + k0 + c * 8;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(base + NPL * XBYTES + p * WBYTES + instr * 1024), 16, 0, 0);
     }
+    if (piece == 0 && l_k == 0) {
+      const float* src = a.bias + l_n0 + wn * TN + lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + BIAS_OFF +
+                                                                                 ((l_ord & 1) * 8 + wave) * 256),
+                                       4, 0, 0);
+    }
+  };
+  auto advance_load = [&]() {
+    if (l_step >= total) return;
+    ++l_step;
+    if (++l_k == nk) {
+      l_k = 0; ++l_ord; l_tile += stride;
+      const int tm = l_tile / tiles_n;
+      l_m0 = tm * BM; l_n0 = (l_tile - tm * tiles_n) * BN;
+    }
+  };
+  auto issue = [&]() {
+#pragma unroll
+    for (int pc = 0; pc < LPT; ++pc) issue_piece(pc);
+    advance_load();
   };
 
   f4_t acc[RN][RM];
@@ -110,105 +147,247 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
 #pragma unroll
     for (int j = 0; j < RM; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-  // fragment addressing: row = tile_base + (lane&15); 16-B chunk = ks*4 + (lane>>4), XOR f(row) = (lane>>1)&(CPR-1)
+  // fragment addressing: row = tile_base + (lane&15); 16-B chunk = (lane>>4), XOR f(row) = (lane>>1)&(CPR-1)
+  static_assert(KS == 1, "one 32-deep MFMA k-step per ring slot");
   const int frow = lane & 15;
   const int fsw = (lane >> 1) & (CPR - 1);
   const int fq = lane >> 4;
-  const int xoff = (wm * TM + frow) * ROWB;
-  const int woff = (wn * TN + frow) * ROWB;
+  const int xoff = (wm * TM + frow) * ROWB + ((fq ^ fsw) & (CPR - 1)) * 16;
+  const int woff = (wn * TN + frow) * ROWB + ((fq ^ fsw) & (CPR - 1)) * 16;
 
-  const int nk = a.K / BK;
-  stage(0, 0);
-  __syncthreads();
+  // The k-step is cut into NCH chunks of JB x NSPLIT MFMAs.  Each chunk first issues global->LDS pieces of the step
+  // being prefetched and the LDS reads of the NEXT chunk's fragments, then its own MFMAs, so memory-instruction issue
+  // and LDS latency sit in the shadow of the matrix pipe.  The LAST chunk of a step is DEFERRED past the step's
+  // barrier (its fragments are already in registers): right after the barrier every wave has MFMAs to issue while
+  // the first fragments of the new step are in flight — the barrier no longer drains the matrix pipe.
+  constexpr int JB = (NSPLIT == 3) ? 4 : RM;
+  constexpr int NJB = RM / JB;
+  constexpr int NCH = NJB * RN;
+  constexpr int XPC = (JB + RN - 1) / RN;          // next-block X fragments fetched per chunk
+  constexpr int PSL = (NCH - 1) < NCH / 2 ? (NCH - 1) : NCH / 2;   // chunk slots that carry pieces (first half)
+  constexpr int PPS = (LPT + PSL - 1) / PSL;               // pieces per slot
+  h8_t xc_h[JB], xc_l[NPL == 2 ? JB : 1], xn_h[JB], xn_l[NPL == 2 ? JB : 1];
+  h8_t wc_h, wc_l, wn_h, wn_l;
 
-  for (int t = 0; t < nk; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nk) stage(cur ^ 1, (t + 1) * BK);
-    const char* xb = smem + cur * STAGE;
-    const char* wb = xb + NPL * XBYTES;
+  auto load_x = [&](const char* xb, int jb, int j, h8_t& h, h8_t& l) {
+    h = *(const h8_t*)(xb + xoff + (jb * JB + j) * 16 * ROWB);
+    if constexpr (NPL == 2) l = *(const h8_t*)(xb + XBYTES + xoff + (jb * JB + j) * 16 * ROWB);
+  };
+  auto load_w = [&](const char* wb, int i, h8_t& h, h8_t& l) {
+    h = *(const h8_t*)(wb + woff + i * 16 * ROWB);
+    if constexpr (NPL == 2) l = *(const h8_t*)(wb + WBYTES + woff + i * 16 * ROWB);
+  };
+  auto mfma_chunk = [&](int c) {       // c is a compile-time constant after unrolling
+    const int jb = c / RN, i = c % RN;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int coff = (((ks * 4 + fq) ^ fsw) & (CPR - 1)) * 16;
-      h8_t xh[RM], wh[RN], xl[NPL == 2 ? RM : 1], wl[NPL == 2 ? RN : 1];
-#pragma unroll
-      for (int j = 0; j < RM; ++j) {
-        xh[j] = *(const h8_t*)(xb + xoff + j * 16 * ROWB + coff);
-        if constexpr (NPL == 2) xl[j] = *(const h8_t*)(xb + XBYTES + xoff + j * 16 * ROWB + coff);
+    for (int j = 0; j < JB; ++j) {
+      if constexpr (NPL == 2) {
+        acc[i][jb * JB + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc_l, xc_h[j], acc[i][jb * JB + j], 0, 0, 0);
+        acc[i][jb * JB + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc_h, xc_l[j], acc[i][jb * JB + j], 0, 0, 0);
       }
+      acc[i][jb * JB + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc_h, xc_h[j], acc[i][jb * JB + j], 0, 0, 0);
+    }
+  };
+  auto pieces = [&](int slot) {        // slot 0 = deferred-chunk position (no pieces), slot s = chunk s-1
+    if (slot == 0) return;
 #pragma unroll
-      for (int i = 0; i < RN; ++i) {
-        wh[i] = *(const h8_t*)(wb + woff + i * 16 * ROWB + coff);
-        if constexpr (NPL == 2) wl[i] = *(const h8_t*)(wb + WBYTES + woff + i * 16 * ROWB + coff);
-      }
+    for (int q = 0; q < PPS; ++q)
+      if ((slot - 1) * PPS + q < LPT && !(a.ablate & 1)) issue_piece((slot - 1) * PPS + q);
+  };
+
+  int c_ord = 0, c_tile = first;
+  // ---- epilogue -------------------------------------------------------------------------------------------------
+  // A lane's accumulator registers are 4 consecutive n of ONE row m (16 rows per register tile): stored directly that
+  // is 32-B pieces of 16 different rows per instruction, which is store-issue bound.  Each 16-row block is therefore
+  // transposed through a 2.3 KB per-wave LDS scratch so that every global instruction moves 8 whole 128-B rows
+  // (16 B per lane), for the fp16 planes as well as for the fp32 residual read-modify-write.
+  char* scr = smem + SCR_OFF + wave * SCR_WAVE;
+  const int rd_row = lane >> 3, rd_ch = lane & 7;
+  auto epilogue = [&]() {
+    const int tm = c_tile / tiles_n, tn = c_tile - tm * tiles_n;
+    const int m0 = tm * BM + wm * TM, n0 = tn * BN + wn * TN;
+    const char* bslot = smem + BIAS_OFF + ((c_ord & 1) * 8 + wave) * 256;
+    f4_t b4[RN];
+#pragma unroll
+    for (int i = 0; i < RN; ++i) b4[i] = *(const f4_t*)(bslot + (i * 16 + 4 * fq) * 4);
+    if constexpr (EPI == ZK_EPI_PATCH) {
 #pragma unroll
       for (int i = 0; i < RN; ++i)
 #pragma unroll
         for (int j = 0; j < RM; ++j) {
-          if constexpr (NPL == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+          const int m = m0 + j * 16 + frow, n = n0 + i * 16 + 4 * fq;
+          const f4_t v = acc[i][j] + b4[i];
+          acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+          if (m >= a.M) continue;
+          const int b = m / ZK_NPATCH, p = m - b * ZK_NPATCH;
+          const f4_t pe = *(const f4_t*)(a.pos + (size_t)(p + 2) * a.N + n);
+          *(f4_t*)(a.resid + ((size_t)b * ZK_SEQ + 2 + p) * a.N + n) = v + pe;
+        }
+    } else if constexpr (EPI == ZK_EPI_RESID) {
+      static_assert(RN == 4, "two halves of two 16-column blocks");
+#pragma unroll
+      for (int j = 0; j < RM; ++j)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+          for (int il = 0; il < 2; ++il) {
+            *(f4_t*)(scr + frow * SCR_STR + il * 64 + fq * 16) = acc[hf * 2 + il][j] + b4[hf * 2 + il];
+            acc[hf * 2 + il][j] = f4_t{0.f, 0.f, 0.f, 0.f};
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();  // (also drains the glds issued above: the compiler emits vmcnt(0) before the barrier)
-  }
-
-  // ---- epilogue: lane holds n = nb + 4*(lane>>4) + {0..3} of token row m = mb + (lane&15) ----
 #pragma unroll
-  for (int i = 0; i < RN; ++i) {
-    const int n = n0 + wn * TN + i * 16 + 4 * fq;
-    const f4_t b4 = *(const f4_t*)(a.bias + n);
-#pragma unroll
-    for (int j = 0; j < RM; ++j) {
-      const int m = m0 + wm * TM + j * 16 + frow;
-      if (m >= a.M) continue;
-      f4_t v = acc[i][j] + b4;
-      if constexpr (EPI == ZK_EPI_RESID) {
-        float* dst = a.resid + (size_t)m * a.N + n;
-        f4_t r = *(const f4_t*)dst;
-        *(f4_t*)dst = r + v;
-      } else if constexpr (EPI == ZK_EPI_PATCH) {
-        const int b = m / ZK_NPATCH, p = m - b * ZK_NPATCH;
-        const f4_t pe = *(const f4_t*)(a.pos + (size_t)(p + 2) * a.N + n);
-        *(f4_t*)(a.resid + ((size_t)b * ZK_SEQ + 2 + p) * a.N + n) = v + pe;
-      } else {
-        if constexpr (EPI == ZK_EPI_GELU) {
-          v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+          for (int t = 0; t < 2; ++t) {
+            const f4_t v = *(const f4_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+            const int m = m0 + j * 16 + rd_row + 8 * t;
+            if (m < a.M) {
+              float* dst = a.resid + (size_t)m * a.N + n0 + hf * 32 + rd_ch * 4;
+              *(f4_t*)dst = *(const f4_t*)dst + v;
+            }
+          }
         }
-        h4_t hi;
-        hi[0] = (half_t)v[0]; hi[1] = (half_t)v[1]; hi[2] = (half_t)v[2]; hi[3] = (half_t)v[3];
-        *(h4_t*)(a.o_hi + (size_t)m * a.N + n) = hi;
-        if (a.o_lo != nullptr && n < a.lo_n_limit) {
-          h4_t lo;
-          lo[0] = (half_t)(v[0] - (float)hi[0]); lo[1] = (half_t)(v[1] - (float)hi[1]);
-          lo[2] = (half_t)(v[2] - (float)hi[2]); lo[3] = (half_t)(v[3] - (float)hi[3]);
-          *(h4_t*)(a.o_lo + (size_t)m * a.N + n) = lo;
+    } else {
+      const bool want_lo = a.o_lo != nullptr && n0 < a.lo_n_limit;
+#pragma unroll
+      for (int j = 0; j < RM; ++j) {
+        h4_t lo4[RN];
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+          f4_t v = acc[i][j] + b4[i];
+          acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+          if constexpr (EPI == ZK_EPI_GELU) {
+            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+          }
+          h4_t hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { hi[e] = (half_t)v[e]; lo4[i][e] = (half_t)(v[e] - (float)hi[e]); }
+          *(h4_t*)(scr + frow * SCR_STR + i * 32 + fq * 8) = hi;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+          const int m = m0 + j * 16 + rd_row + 8 * t;
+          if (m < a.M) *(h8_t*)(a.o_hi + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+        }
+        if (want_lo) {
+#pragma unroll
+          for (int i = 0; i < RN; ++i) *(h4_t*)(scr + frow * SCR_STR + i * 32 + fq * 8) = lo4[i];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+            const int m = m0 + j * 16 + rd_row + 8 * t;
+            if (m < a.M) *(h8_t*)(a.o_lo + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+          }
         }
       }
     }
+    ++c_ord; c_tile += stride;
+  };
+
+  if (total == 0) return;
+  const bool stamp = a.stamps != nullptr && tid == 0;
+  long long* st = a.stamps + (size_t)blockIdx.x * 16;
+  if (stamp) st[0] = (long long)__builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (l_step < total) issue();
+  // first step landed?  (conservative: drain; happens once per launch)
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (stamp) st[1] = (long long)__builtin_amdgcn_s_memtime();
+
+  int c_k = 0;
+  bool epi_pending = false;
+  const bool fine = a.stamps != nullptr && (a.ablate & 8) && lane == 0 && (wave == 0 || wave == 4);
+  long long fs[5] = {0, 0, 0, 0, 0};
+  long long ft = 0;
+#define ZK_FINE(idx)                                                         \
+  if (fine) {                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    const long long now__ = (long long)__builtin_amdgcn_s_memtime();        \
+    fs[idx] += now__ - ft;                                                   \
+    ft = now__;                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                       \
   }
+  if (fine) ft = (long long)__builtin_amdgcn_s_memtime();
+  for (int c_step = 0; c_step < total; ++c_step) {
+    const char* xb = smem + (c_step % NST) * STAGE;
+    const char* wb = xb + NPL * XBYTES;
+    // ---- slot 0: first fragments of this step in flight behind the deferred chunk of the previous step ----
+#pragma unroll
+    for (int j = 0; j < JB; ++j) load_x(xb, 0, j, xn_h[j], xn_l[j]);
+    load_w(wb, 0, wn_h, wn_l);
+    pieces(0);
+    if (c_step > 0) {
+      mfma_chunk(NCH - 1);
+      if (epi_pending) {
+        if (stamp && c_ord < 2) st[2 + 2 * c_ord] = (long long)__builtin_amdgcn_s_memtime();
+        epilogue();
+        if (stamp && c_ord <= 2) st[1 + 2 * c_ord] = (long long)__builtin_amdgcn_s_memtime();
+        epi_pending = false;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ZK_FINE(0)
+#pragma unroll
+    for (int j = 0; j < JB; ++j) { xc_h[j] = xn_h[j]; if constexpr (NPL == 2) xc_l[j] = xn_l[j]; }
+    wc_h = wn_h;
+    if constexpr (NPL == 2) wc_l = wn_l;
+    // ---- chunks 0 .. NCH-2 ----
+#pragma unroll
+    for (int c = 0; c < NCH - 1; ++c) {
+      const int jb = c / RN, i = c % RN;
+      pieces(c + 1);
+      load_w(wb, (c + 1) % RN, wn_h, wn_l);
+      if (jb + 1 < NJB) {
+#pragma unroll
+        for (int q = 0; q < XPC; ++q)
+          if (i * XPC + q < JB) load_x(xb, jb + 1, i * XPC + q, xn_h[i * XPC + q], xn_l[i * XPC + q]);
+      }
+      mfma_chunk(c);
+      __builtin_amdgcn_sched_barrier(0);
+      wc_h = wn_h;
+      if constexpr (NPL == 2) wc_l = wn_l;
+      if (i == RN - 1 && jb + 1 < NJB) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j) { xc_h[j] = xn_h[j]; if constexpr (NPL == 2) xc_l[j] = xn_l[j]; }
+      }
+    }
+    ZK_FINE(1)
+    advance_load();
+    if (++c_k == nk) { c_k = 0; epi_pending = true; }
+    // ---- step c_step+1 must have landed; NST-2 younger steps may stay in flight.  xc/wc now hold the fragments of
+    //      the deferred chunk NCH-1 (read from this slot BEFORE the barrier that frees it) ----
+    if (!(a.ablate & 2)) {
+      if (l_step - c_step - 2 >= NST - 2) wait_vmcnt<INFLIGHT>();
+      else wait_vmcnt<0>();
+    }
+    ZK_FINE(2)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ZK_FINE(3)
+    if (!(a.ablate & 4)) __builtin_amdgcn_s_barrier();
+    ZK_FINE(4)
+  }
+  if (fine) {
+    long long* o = st + (wave == 0 ? 6 : 11);
+    for (int q = 0; q < 5; ++q) o[q] = fs[q];
+  }
+  mfma_chunk(NCH - 1);
+  if (stamp && c_ord < 2) st[2 + 2 * c_ord] = (long long)__builtin_amdgcn_s_memtime();
+  epilogue();
+  if (stamp && c_ord <= 2) st[1 + 2 * c_ord] = (long long)__builtin_amdgcn_s_memtime();
 }
 
 template <int NSPLIT, int EPI>
 void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
-  if constexpr (NSPLIT == 1) {
-    constexpr int BM = 256, BN = 256, BK = 64;
-    constexpr int lds = 2 * (BM + BN) * BK * 2;
-    auto k = gemm_kernel<1, BM, BN, BK, 2, 4, EPI>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
-  } else {
-    constexpr int BM = 256, BN = 128, BK = 32;
-    constexpr int lds = 2 * 2 * (BM + BN) * BK * 2;
-    auto k = gemm_kernel<3, BM, BN, BK, 4, 2, EPI>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
-  }
+  constexpr int BM = 256, BN = 256, BK = 32;
+  constexpr int NST = (NSPLIT == 3) ? 2 : 4;
+  constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
+  constexpr int lds = NST * NPL * (BM + BN) * BK * 2 + 2 * 8 * 256 + 8 * 16 * 144;
+  auto k = gemm_kernel<NSPLIT, BM, BN, BK, 2, 4, NST, EPI>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+  int grid = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
 }
 
 template <int NSPLIT>

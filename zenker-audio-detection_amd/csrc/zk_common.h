@@ -57,6 +57,8 @@ struct zk_gemm_args {
   float* resid;        // [M, N] fp32, in-place += (RESID) ; PATCH: hidden base
   const float* pos;    // PATCH: position embeddings [1214, 768]
   int lo_n_limit;      // STORE: write the lo plane only for n < lo_n_limit
+  long long* stamps;   // diagnostic only (ZK_GEMM_STAMPS): [grid][16] s_memtime stamps, nullptr in production
+  int ablate;          // diagnostic only (ZK_GEMM_ABLATE): timing-only knobs, 0 in production
 };
 
 // launchers (each file owns its kernels)

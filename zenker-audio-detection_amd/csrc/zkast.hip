@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -293,7 +294,7 @@ void run_gemm(zk_ctx* c, int cls, zk_planes x, const half_t* w_hi, const half_t*
   a.x_hi = x.hi; a.x_lo = x.lo; a.w_hi = w_hi; a.w_lo = w_lo; a.bias = bias;
   a.M = M; a.N = N; a.K = K;
   a.o_hi = out.hi; a.o_lo = (nsplit == 3) ? out.lo : nullptr;
-  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit;
+  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.stamps = nullptr; a.ablate = 0;
   zk_launch_gemm(a, epi, nsplit, c->stream);
 }
 
@@ -854,9 +855,37 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   zk_gemm_args a;
   a.x_hi = xh; a.x_lo = nsplit == 3 ? xl : nullptr; a.w_hi = wh; a.w_lo = nsplit == 3 ? wl : nullptr; a.bias = dbias;
   a.M = M; a.N = N; a.K = K; a.o_hi = oh; a.o_lo = nsplit == 3 ? ol : nullptr; a.resid = dres; a.pos = dpos; a.lo_n_limit = N;
+  a.stamps = nullptr;
+  a.ablate = getenv("ZK_GEMM_ABLATE") ? atoi(getenv("ZK_GEMM_ABLATE")) : 0;
+  long long* dstamps = nullptr;
+  if (getenv("ZK_GEMM_STAMPS")) {
+    HIPCHK(c, hipMalloc((void**)&dstamps, 256 * 16 * 8));
+    HIPCHK(c, hipMemset(dstamps, 0, 256 * 16 * 8));
+    a.stamps = dstamps;
+  }
   zk_launch_gemm(a, epi, nsplit, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (dstamps) {
+    std::vector<long long> st(256 * 16);
+    HIPCHK(c, hipMemcpy(st.data(), dstamps, st.size() * 8, hipMemcpyDeviceToHost));
+    double pro = 0, loop0 = 0, epi0 = 0, loop1 = 0, epi1 = 0; int nb = 0, nb1 = 0;
+    for (int b = 0; b < 256; ++b) {
+      const long long* s = &st[(size_t)b * 16];
+      if (!s[0] || !s[2]) continue;
+      pro += (double)(s[1] - s[0]); loop0 += (double)(s[2] - s[1]); epi0 += (double)(s[3] - s[2]); ++nb;
+      if (s[4]) { loop1 += (double)(s[4] - s[3]); epi1 += (double)(s[5] - s[4]); ++nb1; }
+    }
+    if (nb) fprintf(stderr, "[stamps] M=%d N=%d K=%d ns=%d epi=%d blocks=%d: prologue %.0f  loop0 %.0f  epi0 %.0f | loop1 %.0f epi1 %.0f (s_memtime ticks, nb1=%d)\n",
+                    M, N, K, nsplit, epi, nb, pro / nb, loop0 / nb, epi0 / nb, nb1 ? loop1 / nb1 : 0.0, nb1 ? epi1 / nb1 : 0.0, nb1);
+    if (a.ablate & 8) {
+      double f[10] = {0}; int nf = 0;
+      for (int b = 0; b < 256; ++b) { const long long* s = &st[(size_t)b * 16]; if (!s[0] || !s[6]) continue; for (int q = 0; q < 10; ++q) f[q] += (double)s[6 + q]; ++nf; }
+      if (nf) fprintf(stderr, "[fine] per-block totals / steps: wave0 slot0 %.0f chunks %.0f vmcnt %.0f lgkm %.0f barrier %.0f | wave4 slot0 %.0f chunks %.0f vmcnt %.0f lgkm %.0f barrier %.0f (steps=%d)\n",
+                      f[0]/nf/(K/32), f[1]/nf/(K/32), f[2]/nf/(K/32), f[3]/nf/(K/32), f[4]/nf/(K/32), f[5]/nf/(K/32), f[6]/nf/(K/32), f[7]/nf/(K/32), f[8]/nf/(K/32), f[9]/nf/(K/32), K/32);
+    }
+    (void)hipFree(dstamps);
+  }
   if (dres) HIPCHK(c, hipMemcpy(out, dres, no * 4, hipMemcpyDeviceToHost));
   else {
     std::vector<uint16_t> h(no), l(no);
