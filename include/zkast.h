@@ -61,7 +61,10 @@ const char* zk_last_error(zk_ctx* ctx);           /* ctx may be NULL: last error
 int zk_set_stream(zk_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = the context's own stream                  */
 int zk_set_async(zk_ctx* ctx, int enable);
 int zk_synchronize(zk_ctx* ctx);
-int zk_set_micro_batch(zk_ctx* ctx, int32_t windows); /* forward is chunked into micro-batches (default 64)         */
+/* exact last-layer pruning: only tokens 0/1 feed the head (ASTModel.forward:304), so the last layer's attention
+ * queries, O projection and MLP run on those two rows per window only.  Default on; results are unchanged.       */
+int zk_set_prune_last_layer(zk_ctx* ctx, int enable);
+int zk_set_micro_batch(zk_ctx* ctx, int32_t windows); /* forward is chunked into micro-batches; 0 = auto (default)    */
 const char* zk_version(void);
 
 /* ---- model -------------------------------------------------------------------------------------------------- */
@@ -120,6 +123,9 @@ int zk_resample(zk_ctx* ctx, const float* in /*host|device*/, int64_t n_in, int3
 int zk_prof_begin(zk_ctx* ctx);
 int zk_prof_end(zk_ctx* ctx);
 int zk_prof_get(zk_ctx* ctx, const char* name, double* ms, int64_t* launches);
+/* FLOPs the launches of that class EXECUTED algorithmically (2*M*N*K per GEMM launch; 4*Sq*S*64 per head for attention),
+ * i.e. with the exact last-layer pruning taken into account and WITHOUT counting the 3 MFMA passes of ZK_F16X3 */
+int zk_prof_get_flops(zk_ctx* ctx, const char* name, double* flops);
 /* debug tap used by the parity tests: keep the fp32 residual stream of the FIRST micro-batch after encoder layer
  * `layer` (-1 = embeddings output, -2 = off) of the next forward; get copies (n_windows, 1214, 768) to host.        */
 int zk_debug_set_tap(zk_ctx* ctx, int32_t layer);

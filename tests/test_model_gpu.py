@@ -182,3 +182,23 @@ def test_batch_properties_at_full_size():
     feats = orc.extract_features([wins[i] for i in pick], -1.1509622, 3.5340312)
     ref = orc.ast_forward(feats, W)
     assert np.abs(l_a[pick] - ref).max() <= TOL
+
+
+def test_last_layer_pruning_is_exact():
+    """zk_set_prune_last_layer: the last layer runs its queries / O / MLP on tokens 0,1 only — logits must not move."""
+    from zkast import lib, synth
+    model, _ = _model(31, "wide", 0)
+    ctx = lib.get_context(0)
+    rec = synth.synth_recording(18, 16000 + 39 * 8000)
+    ctx.logmel(rec, rec.size, 0, 8000, 16000, 40)
+    ctx.set_prune_last_layer(False)
+    full = model.forward_from_slot(40)
+    ctx.set_prune_last_layer(True)
+    pruned = model.forward_from_slot(40)
+    assert np.array_equal(full, pruned)
+    model.set_compute_mode("f16")
+    a = model.forward_from_slot(40)
+    ctx.set_prune_last_layer(False)
+    b = model.forward_from_slot(40)
+    ctx.set_prune_last_layer(True)
+    assert np.array_equal(a, b)

@@ -29,7 +29,7 @@ constexpr int TILE_B = KT * 128;        // bytes of one [64][64] fp16 image
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict__ qkv_hi,
                                                         const half_t* __restrict__ qkv_lo, half_t* __restrict__ o_hi,
-                                                        half_t* __restrict__ o_lo, int n_windows) {
+                                                        half_t* __restrict__ o_lo, int n_windows, int q_tiles) {
   constexpr bool SPLIT = (NSPLIT == 3);
   constexpr int NIMG = SPLIT ? 3 : 2;     // Kh, [Kl], V
   constexpr int BUF_B = NIMG * TILE_B;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   const int half = lane >> 5;
 
   // XCD-aware bijective remap: the 10 query tiles of one (window, head) share K/V -> keep them on one XCD.
-  const int nwg = NQT * ZK_HEADS * n_windows;
+  const int nwg = q_tiles * ZK_HEADS * n_windows;
   int wg;
   {
     const int bid = blockIdx.x;
@@ -49,9 +49,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     const int xcd = bid & 7, idx = bid >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int qt = wg % NQT;
-  const int head = (wg / NQT) % ZK_HEADS;
-  const int win = wg / (NQT * ZK_HEADS);
+  const int qt = wg % q_tiles;
+  const int head = (wg / q_tiles) % ZK_HEADS;
+  const int win = wg / (q_tiles * ZK_HEADS);
   const size_t tok0 = (size_t)win * S_;
 
   // ---- Q fragments (B operand: lane holds Q[q = lane&31][d = 16ks + 8*half + j]) ----
@@ -221,14 +221,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
 
 }  // namespace
 
-void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit, hipStream_t s) {
+void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit, int q_tiles, hipStream_t s) {
   if (n_windows <= 0) return;
-  const int grid = NQT * ZK_HEADS * n_windows;
+  if (q_tiles <= 0 || q_tiles > NQT) q_tiles = NQT;   // q_tiles < 10: only the first q_tiles*128 query rows (last-layer pruning)
+  const int grid = q_tiles * ZK_HEADS * n_windows;
   if (nsplit == 3) {
     hipLaunchKernelGGL(attention_kernel<3>, dim3(grid), dim3(256), 2 * 3 * TILE_B, s, qkv.hi, qkv.lo, out.hi, out.lo,
-                       n_windows);
+                       n_windows, q_tiles);
   } else {
     hipLaunchKernelGGL(attention_kernel<1>, dim3(grid), dim3(256), 2 * 2 * TILE_B, s, qkv.hi, qkv.lo, out.hi, out.lo,
-                       n_windows);
+                       n_windows, q_tiles);
   }
 }

@@ -59,7 +59,32 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ hidde
   hidden[((size_t)b * ZK_SEQ + r) * ZK_HIDDEN + c] = (r == 0 ? cls[c] : dist[c]) + pos[r * ZK_HIDDEN + c];
 }
 
+// rows 0 (cls) and 1 (distillation) of every window -> compact [2*n_windows, 768] (attention output planes and the
+// fp32 residual stream): the only rows the head consumes, so the last layer's O / MLP GEMMs run on these alone.
+__global__ __launch_bounds__(256) void gather_tok01_kernel(const half_t* __restrict__ a_hi, const half_t* __restrict__ a_lo,
+                                                           const float* __restrict__ hidden, int n_windows,
+                                                           half_t* __restrict__ o_hi, half_t* __restrict__ o_lo,
+                                                           float* __restrict__ h_out) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;       // one thread = 4 channels of one row
+  if (gid >= n_windows * 2 * (ZK_HIDDEN / 4)) return;
+  const int c4 = gid % (ZK_HIDDEN / 4);
+  const int r = gid / (ZK_HIDDEN / 4);                   // b*2 + tok
+  const size_t src = ((size_t)(r >> 1) * ZK_SEQ + (r & 1)) * ZK_HIDDEN + c4 * 4;
+  const size_t dst = (size_t)r * ZK_HIDDEN + c4 * 4;
+  *(h4_t*)(o_hi + dst) = *(const h4_t*)(a_hi + src);
+  if (o_lo) *(h4_t*)(o_lo + dst) = *(const h4_t*)(a_lo + src);
+  *(f4_t*)(h_out + dst) = *(const f4_t*)(hidden + src);
+}
+
 }  // namespace
+
+void zk_launch_gather_tok01(zk_planes att, const float* hidden, int n_windows, zk_planes att_out, float* hidden_out,
+                            hipStream_t s) {
+  if (n_windows <= 0) return;
+  const int total = n_windows * 2 * (ZK_HIDDEN / 4);
+  hipLaunchKernelGGL(gather_tok01_kernel, dim3((total + 255) / 256), dim3(256), 0, s, att.hi, att.lo, hidden, n_windows,
+                     att_out.hi, att_out.lo, hidden_out);
+}
 
 void zk_launch_im2col_compact(const float* feats, int n_frames, const int32_t* win_idx, int n_windows, float mean,
                               float std2, zk_planes out, hipStream_t s) {

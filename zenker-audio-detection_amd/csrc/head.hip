@@ -14,7 +14,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // one wave per window; lane holds 12 channels (c = i*256 + lane*4 + j)
-__global__ __launch_bounds__(64) void head_kernel(const float* __restrict__ hidden, int n_windows,
+__global__ __launch_bounds__(64) void head_kernel(const float* __restrict__ hidden, int rows_per_window, int n_windows,
                                                   const float* __restrict__ lnf_g, const float* __restrict__ lnf_b,
                                                   const float* __restrict__ lnh_g, const float* __restrict__ lnh_b,
                                                   const float* __restrict__ w, const float* __restrict__ bias,
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void head_kernel(const float* __restrict__ hidd
 #pragma unroll
   for (int i = 0; i < 12; ++i) pooled[i] = 0.f;
   for (int tok = 0; tok < 2; ++tok) {
-    const float* xr = hidden + ((size_t)b * ZK_SEQ + tok) * ZK_HIDDEN;
+    const float* xr = hidden + ((size_t)b * rows_per_window + tok) * ZK_HIDDEN;
     float v[12];
     float s = 0.f;
 #pragma unroll
@@ -128,11 +128,11 @@ __global__ __launch_bounds__(1024) void gate_kernel(const float* __restrict__ lo
 
 }  // namespace
 
-void zk_launch_head(const float* hidden, int n_windows, const float* lnf_g, const float* lnf_b, const float* lnh_g,
+void zk_launch_head(const float* hidden, int rows_per_window, int n_windows, const float* lnf_g, const float* lnf_b, const float* lnh_g,
                     const float* lnh_b, const float* w, const float* b, int num_labels, float eps, float* logits,
                     hipStream_t s) {
   if (n_windows <= 0) return;
-  hipLaunchKernelGGL(head_kernel, dim3(n_windows), dim3(64), 0, s, hidden, n_windows, lnf_g, lnf_b, lnh_g, lnh_b, w,
+  hipLaunchKernelGGL(head_kernel, dim3(n_windows), dim3(64), 0, s, hidden, rows_per_window, n_windows, lnf_g, lnf_b, lnh_g, lnh_b, w,
                      b, num_labels, eps, logits);
 }
 

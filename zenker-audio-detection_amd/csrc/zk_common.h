@@ -65,13 +65,15 @@ struct zk_gemm_args {
 void zk_launch_gemm(const zk_gemm_args& a, int epi, int nsplit, hipStream_t s);
 void zk_launch_layernorm(const float* x, int64_t row_stride, const float* gamma, const float* beta, int rows,
                          zk_planes out, float eps, hipStream_t s);
-void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit, hipStream_t s);
+void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit, int q_tiles, hipStream_t s);
+void zk_launch_gather_tok01(zk_planes att, const float* hidden, int n_windows, zk_planes att_out, float* hidden_out,
+                            hipStream_t s);
 void zk_launch_im2col_compact(const float* feats, int n_frames, const int32_t* win_idx, int n_windows, float mean,
                               float std2, zk_planes out, hipStream_t s);
 void zk_launch_im2col_full(const float* input_values, int n_windows, zk_planes out, hipStream_t s);
 void zk_launch_cls_rows(float* hidden, const float* cls, const float* dist, const float* pos, int n_windows,
                         hipStream_t s);
-void zk_launch_head(const float* hidden, int n_windows, const float* lnf_g, const float* lnf_b, const float* lnh_g,
+void zk_launch_head(const float* hidden, int rows_per_window, int n_windows, const float* lnf_g, const float* lnf_b, const float* lnh_g,
                     const float* lnh_b, const float* w, const float* b, int num_labels, float eps, float* logits,
                     hipStream_t s);
 void zk_launch_logmel(const float* audio, int64_t n_samples, int64_t first_start, int64_t hop, int32_t win,

@@ -76,7 +76,7 @@ struct zk_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   bool async = false;
-  int micro_batch = 64;
+  int micro_batch = 0;   // 0 = auto
   std::string err;
   StageModel model[2];
 
@@ -89,7 +89,9 @@ struct zk_ctx {
   // staging + workspace
   DevBuf st_in, st_out, st_idx, audio_dev, s1_logits, s2_logits, gate_idx, gate_cnt, tmp_f32;
   DevBuf hidden;
-  PlaneBuf patchA, xn, qkv, att, mid;
+  PlaneBuf patchA, xn, qkv, att, mid, att_s, xn_s, mid_s;   // *_s: tokens 0/1 only (last-layer pruning)
+  DevBuf hidden_s;
+  bool prune_last = true;
   int ws_windows = 0;
   bool ws_split = false;
 
@@ -102,6 +104,7 @@ struct zk_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   std::vector<std::pair<int, int>> ev_used;  // (class, pool index)
   double prof_ms[P_N] = {0};
+  double prof_flops[P_N] = {0};
   int64_t prof_n[P_N] = {0};
 
   // debug tap
@@ -282,6 +285,11 @@ int ensure_workspace(zk_ctx* c, int windows, bool split) {
   HIPCHK(c, pl(c->qkv, M * 3 * ZK_HIDDEN));
   HIPCHK(c, pl(c->att, M * ZK_HIDDEN));
   HIPCHK(c, pl(c->mid, M * ZK_INTER));
+  const size_t Ms = (size_t)w * 2 + 256;
+  HIPCHK(c, c->hidden_s.ensure(Ms * ZK_HIDDEN * 4));
+  HIPCHK(c, pl(c->att_s, Ms * ZK_HIDDEN));
+  HIPCHK(c, pl(c->xn_s, Ms * ZK_HIDDEN));
+  HIPCHK(c, pl(c->mid_s, Ms * ZK_INTER));
   c->ws_windows = w;
   c->ws_split = sp;
   return ZK_OK;
@@ -290,6 +298,7 @@ int ensure_workspace(zk_ctx* c, int windows, bool split) {
 void run_gemm(zk_ctx* c, int cls, zk_planes x, const half_t* w_hi, const half_t* w_lo, const float* bias, int M, int N,
               int K, int epi, int nsplit, zk_planes out, float* resid, const float* pos, int lo_n_limit) {
   ProfScope ps(c, cls);
+  if (c->prof) c->prof_flops[cls] += 2.0 * M * (double)N * K;
   zk_gemm_args a;
   a.x_hi = x.hi; a.x_lo = x.lo; a.w_hi = w_hi; a.w_lo = w_lo; a.bias = bias;
   a.M = M; a.N = N; a.K = K;
@@ -316,12 +325,36 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
     HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
     c->tap_windows = nb;
   }
+  bool pruned = false;
   for (int l = 0; l < sm.n_layers; ++l) {
     const LayerW& L = sm.L[l];
+    // Only tokens 0/1 reach the head (ASTModel.forward:304), so in the LAST layer the queries, the attention output
+    // projection and the MLP are needed for those two rows only (exact: same arithmetic per row).  K/V still need every
+    // token.  Disabled while a debug tap wants the full residual stream of that layer.
+    const bool last = (l == sm.n_layers - 1) && c->prune_last && c->tap_layer != l;
     { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, M, xn, sm.eps, c->stream); }
     run_gemm(c, P_GEMM_QKV, xn, L.wqkv_hi, L.wqkv_lo, L.bqkv, M, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv,
              nullptr, nullptr, 2 * ZK_HIDDEN);
-    { ProfScope ps(c, P_ATTN); zk_launch_attention(qkv, att, nb, ns, c->stream); }
+    {
+      ProfScope ps(c, P_ATTN);
+      const int qt = last ? 1 : 10;
+      if (c->prof) c->prof_flops[P_ATTN] += (double)nb * ZK_HEADS * 4.0 * (qt == 1 ? 128.0 : (double)ZK_SEQ) * ZK_SEQ * ZK_HEAD_DIM;
+      zk_launch_attention(qkv, att, nb, ns, qt, c->stream);
+    }
+    if (last) {
+      zk_planes att_s = c->att_s.get(sp), xn_s = c->xn_s.get(sp), mid_s = c->mid_s.get(sp);
+      float* hs = c->hidden_s.as<float>();
+      { ProfScope ps(c, P_EMBED); zk_launch_gather_tok01(att, hidden, nb, att_s, hs, c->stream); }
+      run_gemm(c, P_GEMM_O, att_s, L.wo_hi, L.wo_lo, L.bo, 2 * nb, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
+               zk_planes{nullptr, nullptr}, hs, nullptr, 0);
+      { ProfScope ps(c, P_LN); zk_launch_layernorm(hs, ZK_HIDDEN, L.ln2_g, L.ln2_b, 2 * nb, xn_s, sm.eps, c->stream); }
+      run_gemm(c, P_GEMM_FC1, xn_s, L.w1_hi, L.w1_lo, L.b1, 2 * nb, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid_s, nullptr,
+               nullptr, ZK_INTER);
+      run_gemm(c, P_GEMM_FC2, mid_s, L.w2_hi, L.w2_lo, L.b2, 2 * nb, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
+               zk_planes{nullptr, nullptr}, hs, nullptr, 0);
+      pruned = true;
+      continue;
+    }
     run_gemm(c, P_GEMM_O, att, L.wo_hi, L.wo_lo, L.bo, M, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
              zk_planes{nullptr, nullptr}, hidden, nullptr, 0);
     { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln2_g, L.ln2_b, M, xn, sm.eps, c->stream); }
@@ -337,8 +370,8 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
   }
   {
     ProfScope ps(c, P_HEAD);
-    zk_launch_head(hidden, nb, sm.lnf_g, sm.lnf_b, sm.lnh_g, sm.lnh_b, sm.head_w, sm.head_b, sm.num_labels, sm.eps,
-                   d_logits, c->stream);
+    zk_launch_head(pruned ? c->hidden_s.as<float>() : hidden, pruned ? 2 : ZK_SEQ, nb, sm.lnf_g, sm.lnf_b, sm.lnh_g,
+                   sm.lnh_b, sm.head_w, sm.head_b, sm.num_labels, sm.eps, d_logits, c->stream);
   }
   HIPCHK(c, hipGetLastError());
   return ZK_OK;
@@ -348,7 +381,15 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
 int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d_idx, int B, float* d_logits) {
   StageModel& sm = c->model[stage];
   const bool sp = sm.mode == 3;
-  const int mbs = c->micro_batch;
+  // micro_batch == 0: pick the size whose 256-row tile count fills the 256 persistent workgroups with the least
+  // round-up waste for the N=768 GEMMs (3 column tiles): tiles_m*3 just below a multiple of 256.
+  int mbs = c->micro_batch;
+  if (mbs <= 0) {
+    static const int good[] = {107, 89, 71, 53, 35, 17};
+    mbs = 17;
+    for (int g : good) if (B >= g) { mbs = g; break; }
+    if (B < 17) mbs = B;
+  }
   int rc = ensure_workspace(c, B < mbs ? B : mbs, sp);
   if (rc) return rc;
   bool tapped = false;
@@ -454,7 +495,8 @@ void zk_destroy(zk_ctx* c) {
   for (DevBuf* b : {&c->feat, &c->st_in, &c->st_out, &c->st_idx, &c->audio_dev, &c->s1_logits, &c->s2_logits, &c->gate_idx,
                     &c->gate_cnt, &c->tmp_f32, &c->hidden, &c->rs_kern, &c->tap})
     b->release();
-  for (PlaneBuf* b : {&c->patchA, &c->xn, &c->qkv, &c->att, &c->mid}) { b->hi.release(); b->lo.release(); }
+  c->hidden_s.release();
+  for (PlaneBuf* b : {&c->patchA, &c->xn, &c->qkv, &c->att, &c->mid, &c->att_s, &c->xn_s, &c->mid_s}) { b->hi.release(); b->lo.release(); }
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -471,7 +513,7 @@ int zk_set_async(zk_ctx* c, int e) { if (!c) return ZK_E_ARG; c->async = e != 0;
 int zk_synchronize(zk_ctx* c) { if (!c) return ZK_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return ZK_OK; }
 int zk_set_micro_batch(zk_ctx* c, int32_t w) {
   if (!c) return ZK_E_ARG;
-  if (w < 1 || w > 4096) return fail(c, ZK_E_ARG, "micro batch %d out of range [1,4096]", w);
+  if (w < 0 || w > 4096) return fail(c, ZK_E_ARG, "micro batch %d out of range [0,4096] (0 = auto)", w);
   c->micro_batch = w;
   return ZK_OK;
 }
@@ -772,7 +814,7 @@ int zk_prof_begin(zk_ctx* c) {
   if (!c) return ZK_E_ARG;
   c->prof = true;
   c->ev_used.clear();
-  for (int i = 0; i < P_N; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  for (int i = 0; i < P_N; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; c->prof_flops[i] = 0; }
   return ZK_OK;
 }
 int zk_prof_end(zk_ctx* c) {
@@ -795,6 +837,14 @@ int zk_prof_get(zk_ctx* c, const char* name, double* ms, int64_t* launches) {
     if (!strcmp(name, kProfNames[i])) { if (ms) *ms = c->prof_ms[i]; if (launches) *launches = c->prof_n[i]; return ZK_OK; }
   return fail(c, ZK_E_ARG, "unknown profile class '%s'", name);
 }
+
+int zk_prof_get_flops(zk_ctx* c, const char* name, double* flops) {
+  if (!c || !name || !flops) return ZK_E_ARG;
+  for (int i = 0; i < P_N; ++i)
+    if (!strcmp(name, kProfNames[i])) { *flops = c->prof_flops[i]; return ZK_OK; }
+  return fail(c, ZK_E_ARG, "unknown profile class '%s'", name);
+}
+int zk_set_prune_last_layer(zk_ctx* c, int enable) { if (!c) return ZK_E_ARG; c->prune_last = enable != 0; return ZK_OK; }
 
 int zk_debug_set_tap(zk_ctx* c, int32_t layer) { if (!c) return ZK_E_ARG; c->tap_layer = layer; c->tap_windows = 0; return ZK_OK; }
 int zk_debug_get_tap(zk_ctx* c, float* out, int32_t n_windows) {
@@ -909,7 +959,7 @@ int zk_test_attention(zk_ctx* c, const float* qkv, int32_t W, int32_t nsplit, fl
   HIPCHK(c, hipMemset(ol, 0, no * 2));
   HIPCHK(c, hipMemcpy(dq, qkv, nq * 4, hipMemcpyHostToDevice));
   zk_launch_split_f32(dq, (int64_t)nq, 1.f, qh, ql, c->stream);
-  zk_launch_attention(zk_planes{qh, nsplit == 3 ? ql : nullptr}, zk_planes{oh, nsplit == 3 ? ol : nullptr}, W, nsplit, c->stream);
+  zk_launch_attention(zk_planes{qh, nsplit == 3 ? ql : nullptr}, zk_planes{oh, nsplit == 3 ? ol : nullptr}, W, nsplit, 0, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<uint16_t> h(no), l(no);

@@ -25,9 +25,9 @@ COMPUTE_MODES = {"f16": ZK_F16, "f16x3": ZK_F16X3, 1: ZK_F16, 3: ZK_F16X3}
 # every symbol include/zkast.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
     "zk_create", "zk_destroy", "zk_last_error", "zk_set_stream", "zk_set_async", "zk_synchronize",
-    "zk_set_micro_batch", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_fx",
+    "zk_set_micro_batch", "zk_set_prune_last_layer", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_fx",
     "zk_logmel", "zk_features_expand", "zk_features_get", "zk_ast_forward", "zk_softmax", "zk_two_stage", "zk_gate",
-    "zk_resample", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_debug_set_tap", "zk_debug_get_tap",
+    "zk_resample", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_prof_get_flops", "zk_debug_set_tap", "zk_debug_get_tap",
     "zk_test_layernorm", "zk_test_gemm", "zk_test_attention",
 ]
 
@@ -79,6 +79,7 @@ def load_library() -> C.CDLL:
             "zk_set_async": (C.c_int, [vp, C.c_int]),
             "zk_synchronize": (C.c_int, [vp]),
             "zk_set_micro_batch": (C.c_int, [vp, i32]),
+            "zk_set_prune_last_layer": (C.c_int, [vp, C.c_int]),
             "zk_version": (C.c_char_p, []),
             "zk_model_load": (C.c_int, [vp, C.c_int, C.POINTER(TensorDesc), i32, C.POINTER(ASTConfigC), f32, f32, i32]),
             "zk_model_set_compute_mode": (C.c_int, [vp, C.c_int, i32]),
@@ -94,6 +95,7 @@ def load_library() -> C.CDLL:
             "zk_prof_begin": (C.c_int, [vp]),
             "zk_prof_end": (C.c_int, [vp]),
             "zk_prof_get": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
+            "zk_prof_get_flops": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double)]),
             "zk_debug_set_tap": (C.c_int, [vp, i32]),
             "zk_debug_get_tap": (C.c_int, [vp, vp, i32]),
             "zk_test_layernorm": (C.c_int, [vp, vp, vp, vp, i32, f32, i32, vp]),
@@ -159,6 +161,9 @@ class Context:
     # ---- configuration ----
     def set_micro_batch(self, windows: int):
         self._chk(self.lib.zk_set_micro_batch(self.h, int(windows)), "zk_set_micro_batch")
+
+    def set_prune_last_layer(self, enable: bool):
+        self._chk(self.lib.zk_set_prune_last_layer(self.h, int(bool(enable))), "zk_set_prune_last_layer")
 
     def set_stream(self, hip_stream: int | None):
         self._chk(self.lib.zk_set_stream(self.h, C.c_void_p(hip_stream or 0)), "zk_set_stream")
@@ -300,7 +305,9 @@ class Context:
         for name in PROF_CLASSES:
             ms, n = C.c_double(), C.c_int64()
             self._chk(self.lib.zk_prof_get(self.h, name.encode(), C.byref(ms), C.byref(n)), "zk_prof_get")
-            out[name] = (ms.value, n.value)
+            fl = C.c_double()
+            self._chk(self.lib.zk_prof_get_flops(self.h, name.encode(), C.byref(fl)), "zk_prof_get_flops")
+            out[name] = (ms.value, n.value, fl.value)
         return out
 
     def debug_tap(self, layer: int):
