@@ -13,7 +13,9 @@
 //  * K/V tiles are prefetched global->VGPR during the MFMA phase and written to the other LDS buffer after it.
 //  * NSPLIT=3: q and k are (hi, lo) fp16 pairs, Sᵀ += Kh·Qh + Kl·Qh + Kh·Ql (the scores feed exp(), which
 //    amplifies operand rounding); P·V stays single-pass (measured contribution 8e-5 on the logits).
-//  * softmax in the log2 domain (v_exp_f32), fp32 running max / sum, keys >= 1214 of the last tile masked.
+//  * softmax in the log2 domain (v_exp_f32): the scale is folded into q, the negated running max is the C operand of
+//    the score MFMAs (no per-score subtract), O/l are rescaled only when the max moves by more than 2^8 (deferred
+//    rescale); fp32 running max / sum, keys >= 1214 of the last tile masked.
 #include "zk_common.h"
 
 namespace {
@@ -64,6 +66,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     for (int ks = 0; ks < 4; ++ks) {
       qh[ks] = *(const h8_t*)(qkv_hi + off + ks * 16);
       if constexpr (SPLIT) ql[ks] = *(const h8_t*)(qkv_lo + off + ks * 16);
+      // fold the softmax scale and the change to the log2 domain into q once: q <- q * (d^-1/2 * log2 e)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float qf = (float)qh[ks][e];
+        if constexpr (SPLIT) qf += (float)ql[ks][e];
+        qf *= 0.125f * 1.4426950408889634f;
+        qh[ks][e] = (half_t)qf;
+        if constexpr (SPLIT) ql[ks][e] = (half_t)(qf - (float)qh[ks][e]);
+      }
     }
   }
 
@@ -110,8 +121,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   f16_t oacc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
-  float m_run = -1e30f, l_run = 0.f;
-  const float sc = 0.125f * 1.4426950408889634f;
+  // running max m_run (log2 domain) is kept NEGATED in a 16-register vector that is the C operand of each score
+  // block's first MFMA: the accumulator then holds s - m_run directly and exp2 needs no subtraction.  m_run only
+  // moves when some row's block maximum exceeds it by more than RESCALE_THR (p <= 2^8 is harmless in fp16/fp32);
+  // that rare path rescales O and l (T13-style deferred rescale, wave-uniform branch).
+  constexpr float RESCALE_THR = 8.0f;
+  f16_t negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+  float m_run = 0.f, l_run = 0.f;
 
   load_tile(0);
   store_tile(0);
@@ -123,56 +141,60 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     const char* kb_base = smem + cur * BUF_B;
     const char* vb_base = kb_base + (NIMG - 1) * TILE_B;
 
-    // ---- scores: two 32-key blocks ----
+    // ---- scores minus running max: two 32-key blocks ----
     f16_t sacc[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int ofs = kb * 32 * 128 + kfrag_row + (((2 * ks + half) ^ kfrag_sw) << 4);
         const h8_t kh = *(const h8_t*)(kb_base + ofs);
         if constexpr (SPLIT) {
           const h8_t kl = *(const h8_t*)(kb_base + TILE_B + ofs);
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sacc[kb], 0, 0, 0);
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], ks == 0 ? negm : sacc[kb], 0, 0, 0);
           sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc[kb], 0, 0, 0);
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc[kb], 0, 0, 0);
+        } else {
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], ks == 0 ? negm : sacc[kb], 0, 0, 0);
         }
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc[kb], 0, 0, 0);
       }
     }
 
     // ---- online softmax (log2 domain); lane = query, registers = keys ----
-    float mx = -1e30f;
+    if (kt == NKT - 1) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float t = sacc[kb][r] * sc;
-        if (kt == NKT - 1) {
+        for (int r = 0; r < 16; ++r) {
           const int key = kt * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (key >= S_) t = -1e30f;
+          if (key >= S_) sacc[kb][r] = -1e30f;
         }
-        sacc[kb][r] = t;
-        mx = fmaxf(mx, t);
-      }
+    }
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    if (kt == 0 || !__all(mx <= RESCALE_THR)) {
+      const float delta = (kt == 0) ? mx : fmaxf(mx, 0.f);
+      const float alpha = (kt == 0) ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+      m_run += delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[0][r] -= delta; sacc[1][r] -= delta; }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; negm[i] = -m_run; }
+      l_run *= alpha;
+    }
     float psum = 0.f;
     h8_t pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(sacc[kb][r]);
         psum += p;
         pf[kb][r >> 3][r & 7] = (half_t)p;
       }
-    l_run = fmaf(l_run, alpha, psum);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+    l_run += psum;
 
     // ---- Oᵀ[d][q] += Vᵀ · Pᵀ ----
 #pragma unroll
