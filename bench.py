@@ -142,6 +142,17 @@ def main():
     roofline = {"kernel": dom, "bound": "mfma", "achieved": roof_all[dom]["tflops"], "peak": PEAK_F16_DENSE / 1e12,
                 "unit": "TFLOP/s", "frac": roof_all[dom]["tflops"] * 1e12 / PEAK_F16_DENSE, "traffic": None,
                 "ms_per_launch": roof_all[dom]["ms_per_launch"], "launches": roof_all[dom]["launches"]}
+    # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; the value is the one
+    # measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH correction applied) and
+    # committed under profiles/ (same kernel, micro-batch 107)
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")))["kernels"]
+        key = {"gemm_fc1": "gemm_fc1(gelu)", "gemm_qkv": "gemm_qkv(store)", "gemm_fc2": "gemm_resid(o,fc2)",
+               "gemm_o": "gemm_resid(o,fc2)", "attention": "attention"}[dom]
+        roofline["traffic"] = tr[key]["hbm_bytes_per_launch_corrected"]
+        roofline["traffic_source"] = "profiles/r01_b_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
+    except Exception:
+        pass
     e2e_flops = value / world * (1.0 + K / B) * FLOP_PER_WINDOW_STAGE
     out = {
         "metric": "1-s audio windows/sec two-stage (mel+ASTx2)", "value": value, "unit": "windows/s",
