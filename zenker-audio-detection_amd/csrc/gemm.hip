@@ -39,6 +39,15 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erf_v);
 }
 
+// make wave-uniformity of a pointer provable to the compiler, so that  ptr + zext(u32 lane offset)  selects the
+// SGPR-base + VGPR-offset addressing mode
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long g = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)g);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
+  return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -94,6 +103,27 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
   // load cursor (runs NST-1 steps ahead of the compute cursor)
   int l_step = 0, l_k = 0, l_ord = 0, l_tile = first;
   int l_m0 = (first / tiles_n) * BM, l_n0 = (first % tiles_n) * BN;
+  // per-lane byte offsets of the pieces inside a tile's row panel: computed once (W) / once per tile (X, because of
+  // the M-tail clamp), so that a piece is just  s_add base ; s_mov m0 ; global_load_lds v_off, s[base]  — no per-piece
+  // vector address arithmetic in the k-loop (it was costing ~90 issue cycles per piece).
+  unsigned xoffs[XI], woffs[WI];
+  auto set_xoffs = [&]() {
+#pragma unroll
+    for (int q = 0; q < XI; ++q) {
+      const int row = (q * 8 + wave) * RPI + srow;
+      int grow = l_m0 + row;
+      grow = grow < a.M ? grow : a.M - 1;
+      const int c = schunk ^ ((row >> 1) & (CPR - 1));
+      xoffs[q] = (unsigned)(grow - l_m0) * (unsigned)(a.K * 2) + (unsigned)(c * 16);
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < WI; ++q) {
+    const int row = (q * 8 + wave) * RPI + srow;
+    const int c = schunk ^ ((row >> 1) & (CPR - 1));
+    woffs[q] = (unsigned)row * (unsigned)(a.K * 2) + (unsigned)(c * 16);
+  }
+  set_xoffs();
   auto issue_piece = [&](int piece) {      // piece is a compile-time constant after unrolling
     if (l_step >= total) return;
     char* base = smem + (l_step % NST) * STAGE;
@@ -101,21 +131,15 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
     const int k0 = l_k * BK;
     if (q < XI) {
       const int instr = q * 8 + wave;
-      const int row = instr * RPI + srow;
-      int grow = l_m0 + row;
-      grow = grow < a.M ? grow : a.M - 1;
-      const int c = schunk ^ ((row >> 1) & (CPR - 1));
-      const half_t* src = xp[p] + (size_t)grow * a.K + k0 + c * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+      const char* gb = uniform_ptr((const char*)(xp[p] + (size_t)l_m0 * a.K + k0));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + xoffs[q]),
                                        (__attribute__((address_space(3))) void*)(base + p * XBYTES + instr * 1024),
                                        16, 0, 0);
     } else {
       const int instr = (q - XI) * 8 + wave;
-      const int row = instr * RPI + srow;
-      const int c = schunk ^ ((row >> 1) & (CPR - 1));
-      const half_t* src = wp[p] + (size_t)(l_n0 + row) * a.K + k0 + c * 8;
+      const char* gb = uniform_ptr((const char*)(wp[p] + (size_t)l_n0 * a.K + k0));
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)src,
+          (const __attribute__((address_space(1))) void*)(gb + woffs[q - XI]),
           (__attribute__((address_space(3))) void*)(base + NPL * XBYTES + p * WBYTES + instr * 1024), 16, 0, 0);
     }
     if (piece == 0 && l_k == 0) {
@@ -133,6 +157,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
       l_k = 0; ++l_ord; l_tile += stride;
       const int tm = l_tile / tiles_n;
       l_m0 = tm * BM; l_n0 = (l_tile - tm * tiles_n) * BN;
+      set_xoffs();
     }
   };
   auto issue = [&]() {
