@@ -176,6 +176,50 @@ def main():
     run_case("argmax_none_evaluated", [[0.4, 0.6], [0.45, 0.55]], 0.7, 0.5, [[0.5, 0.5]] * 2)
     run_case("cache_argmax", s1, 0.5, 0.8, s2, use_argmax=True)
     run_case("cache_min_prob", s1, 0.5, 0.5, s2, min_prob=0.75)
+    # ---------------- F6: patient-level aggregation (utils/aggregate_2stage_results.py) + batch-driver helpers -------
+    import contextlib, io, tempfile
+    spec = importlib.util.spec_from_file_location("agg_ref", "/root/reference/utils/aggregate_2stage_results.py")
+    agg_ref = importlib.util.module_from_spec(spec); sys.modules["agg_ref"] = agg_ref; spec.loader.exec_module(agg_ref)
+    spec = importlib.util.spec_from_file_location("batch_ref", os.path.join(REF, "run_batch_simple_2stage.py"))
+    batch_ref = importlib.util.module_from_spec(spec); sys.modules["batch_ref"] = batch_ref; spec.loader.exec_module(batch_ref)
+    patients = [("101", "Healthy", 0.10, 40), ("102", "Healthy", 0.60, 30), ("103", "Zenker", 0.50, 25),
+                ("104", "Zenker", 0.20, 50), ("105", "Zenker", None, 0), ("106", "Other", 0.9, 10),
+                ("107", "Zenker", 0.95, 12)]
+    agg_inputs, agg_expected = {}, {}
+    with tempfile.TemporaryDirectory() as td:
+        for pid, cls, ratio, sw in patients:
+            doc = {"aggregate": {"files_used": [f"/data/Long/{cls}/{pid}/a.wav", f"/data/Long/{cls}/{pid}/b.wav"],
+                                 "total_windows": 100, "total_swallow_windows": sw,
+                                 "total_zenker_windows": 0 if ratio is None else int(round(ratio * sw)),
+                                 "total_healthy_windows": 0, "overall_zenker_ratio_over_swallow": ratio}}
+            agg_inputs[pid] = doc
+            json.dump(doc, open(os.path.join(td, f"{pid}_2stage.json"), "w"))
+        json.dump({"x": 1}, open(os.path.join(td, "batch_fold1_2stage.json"), "w"))
+        for thr in (0.5, 0.3):
+            ns = types.SimpleNamespace(outputs_dir=td, threshold=thr, csv=None, json=None, verbose=False, store_output=False)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                agg_ref.aggregate(ns)
+            summ = json.loads(buf.getvalue())
+            summ.pop("outputs_dir")
+            agg_expected[str(thr)] = summ
+        ids_txt = "Healthy/224\n\nZenker/006\n  Healthy/Sub/31  \n"
+        open(os.path.join(td, "ids.txt"), "w").write(ids_txt)
+        ids_expected = batch_ref.read_ids(os.path.join(td, "ids.txt"))
+    thr_cfg = {"folds": {"1": {"stage1": {"threshold": 0.61}, "stage2": {"threshold": 0.42}}, "2": {"stage2": {"threshold": 0.7}}},
+               "thresholds": {"stage1": {"threshold": 0.55}}}
+    thr_expected = {}
+    for fold in (1, 2, 3):
+        ns = types.SimpleNamespace(long_audio_root="/d", pattern="*.wav", fold=fold, window_sec=1.0, hop_sec=0.5,
+                                   stage1_model_root=None, stage2_model_root=None, stage1_forward_min_prob=None,
+                                   stage2_argmax=False, output_dir=None, plot=False, extra=None)
+        cmd = batch_ref.build_cmd(ns, "006", thr_cfg)
+        thr_expected[str(fold)] = {k[2:].replace("-", "_"): float(cmd[cmd.index(k) + 1])
+                                   for k in ("--stage1-threshold", "--stage2-threshold") if k in cmd}
+    json.dump({"agg_inputs": agg_inputs, "agg_expected": agg_expected, "ids_text": ids_txt, "ids_expected": ids_expected,
+               "threshold_config": thr_cfg, "thresholds_expected": thr_expected},
+              open(os.path.join(HERE, "batch_aggregate.json"), "w"), indent=1)
+
     meta = {"sampling_rate_error_prefix": sr_err, "cases": cases,
             "transformers": __import__("transformers").__version__, "torch": torch.__version__,
             "numpy": np.__version__}

@@ -145,3 +145,46 @@ def test_shard_ranges_partition(n, world):
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     sizes = [hi - lo for lo, hi in spans]
     assert max(sizes) - min(sizes) <= 1
+
+
+# ---- batch driver + patient aggregation, against fixtures produced by the reference's own code ----
+@pytest.fixture(scope="module")
+def BA(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "batch_aggregate.json")))
+
+
+def test_read_ids_and_threshold_resolution(BA, tmp_path):
+    from zkast import batch
+    p = tmp_path / "test_ids_fold1.txt"
+    p.write_text(BA["ids_text"])
+    assert batch.read_ids(str(p)) == BA["ids_expected"]
+    for fold, exp in BA["thresholds_expected"].items():
+        assert batch.resolve_thresholds(BA["threshold_config"], int(fold)) == exp
+    assert batch.resolve_thresholds(None, 1) == {}
+    assert batch.load_threshold_config(str(tmp_path / "nope.json")) is None
+
+
+def test_aggregate_matches_reference(BA, tmp_path):
+    from zkast import aggregate as agg
+    for pid, doc in BA["agg_inputs"].items():
+        json.dump(doc, open(tmp_path / f"{pid}_2stage.json", "w"))
+    json.dump({"x": 1}, open(tmp_path / "batch_fold1_2stage.json", "w"))
+    for thr, exp in BA["agg_expected"].items():
+        summ, rows = agg.aggregate(str(tmp_path), float(thr))
+        summ.pop("outputs_dir")
+        assert summ == exp
+        assert len(rows) == exp["num_patient_results"]
+    assert agg.infer_ground_truth([]) == "Unknown" and agg.parse_patient_id("/x/006_2stage.json") == "006"
+
+
+def test_batch_skip_dry_run_and_error_isolation(tmp_path):
+    from zkast import batch
+    out = tmp_path / "out"
+    out.mkdir()
+    (out / "p1_2stage.json").write_text("{}")
+    logs = []
+    st = batch.run_batch(["p1", "p2"], str(tmp_path), None, None, None, None, str(out), dry_run=True, log=logs.append)
+    assert st == {"p1": "skip", "p2": "dry-run"}
+    # no files for p2 -> the error is logged and the loop goes on (reference: non-zero exit is logged, loop continues)
+    st = batch.run_batch(["p2", "p1"], str(tmp_path), None, None, None, None, str(out), log=logs.append)
+    assert st == {"p2": "error", "p1": "skip"} and any("[ERROR] patient p2" in l for l in logs)
