@@ -220,7 +220,9 @@ def main():
                "threshold_config": thr_cfg, "thresholds_expected": thr_expected},
               open(os.path.join(HERE, "batch_aggregate.json"), "w"), indent=1)
 
-    meta = {"sampling_rate_error_prefix": sr_err, "cases": cases,
+    fx_dict = ASTFeatureExtractor(mean=S1_MEAN, std=S1_STD).to_dict()
+    fx_fp = refc.get_fx_fingerprint(ASTFeatureExtractor(mean=S1_MEAN, std=S1_STD))
+    meta = {"sampling_rate_error_prefix": sr_err, "cases": cases, "fx_to_dict": fx_dict, "fx_fingerprint": fx_fp,
             "transformers": __import__("transformers").__version__, "torch": torch.__version__,
             "numpy": np.__version__}
     json.dump(meta, open(os.path.join(HERE, "cascade_cases.json"), "w"), indent=1, default=lambda o: float(o))

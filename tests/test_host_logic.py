@@ -188,3 +188,20 @@ def test_batch_skip_dry_run_and_error_isolation(tmp_path):
     # no files for p2 -> the error is logged and the loop goes on (reference: non-zero exit is logged, loop continues)
     st = batch.run_batch(["p2", "p1"], str(tmp_path), None, None, None, None, str(out), log=logs.append)
     assert st == {"p2": "error", "p1": "skip"} and any("[ERROR] patient p2" in l for l in logs)
+
+
+def test_feature_cache_keys_match_reference(cases, tmp_path):
+    """fingerprint / to_dict equal the real ASTFeatureExtractor's (fixture from transformers 5.15), so `.pt` caches are
+    interchangeable with the reference's cached variant."""
+    from zkast import cache
+    fx = ZkASTFeatureExtractor(mean=-1.1509622, std=3.5340312)
+    assert fx.to_dict() == cases["fx_to_dict"]
+    assert cache.get_fx_fingerprint(fx) == cases["fx_fingerprint"]
+    wav = tmp_path / "rec.wav"
+    pl.write_wav_pcm16(str(wav), np.zeros(16000, np.float32), 16000)
+    fp = cache.get_fx_fingerprint(fx)
+    p1 = cache.build_cache_path(str(tmp_path), str(wav), 1.0, 0.5, 16000, fp)
+    assert os.path.basename(p1).startswith("rec_") and p1.endswith(".pt") and len(os.path.basename(p1)) == len("rec_") + 16 + 3
+    meta = cache.build_base_metadata(str(wav), 1.0, 0.5, 1, 16000, fp)
+    assert meta["audio_size"] == os.path.getsize(wav) and meta["extractor_fingerprint"] == fp
+    assert cache.build_cache_path(str(tmp_path), str(wav), 1.0, 0.25, 16000, fp) != p1

@@ -202,3 +202,28 @@ def test_last_layer_pruning_is_exact():
     b = model.forward_from_slot(40)
     ctx.set_prune_last_layer(True)
     assert np.array_equal(a, b)
+
+
+def test_feature_cache_roundtrip_and_probs_from_features(tmp_path):
+    """cached variant (..._cache.py:127-208): features computed once, stored as the reference's `.pt` bundle, re-loaded,
+    and forward_probs_from_features on them equals forward_probs on the windows."""
+    import torch
+    from zkast import ZkASTFeatureExtractor, cache, forward_probs, pipeline, synth
+    model, _ = _model(12, "init", 0)
+    fx = ZkASTFeatureExtractor(mean=-1.1509622, std=3.5340312)
+    rec = synth.synth_recording(21, 16000 + 5 * 8000)
+    wav = str(tmp_path / "rec.wav")
+    pipeline.write_wav_pcm16(wav, rec, 16000)
+    audio = pipeline.load_audio(wav)
+    wins = pipeline.window_audio(audio, 1.0, 0.5)
+    logs = []
+    f1 = cache.load_or_compute_features(wav, wins, fx, 1.0, 0.5, 4, str(tmp_path / "c"), log=logs.append)
+    assert tuple(f1.shape) == (6, 1024, 128) and f1.dtype == torch.float32 and any("Saved" in l for l in logs)
+    f2 = cache.load_or_compute_features(wav, wins, fx, 1.0, 0.5, 4, str(tmp_path / "c"), log=logs.append)
+    assert any("Loaded" in l for l in logs) and torch.equal(f1, f2)
+    bundle = torch.load(cache.build_cache_path(str(tmp_path / "c"), wav, 1.0, 0.5, 16000, cache.get_fx_fingerprint(fx)))
+    assert set(bundle) == {"metadata", "features"} and bundle["metadata"]["feature_shape"] == [6, 1024, 128]
+    pa = cache.forward_probs_from_features(model, f2, 4)
+    pb = forward_probs(model, fx, wins, 4)
+    assert np.array_equal(pa, pb)
+    assert cache.forward_probs_from_features(model, f2[:0], 4).shape == (0, 0)

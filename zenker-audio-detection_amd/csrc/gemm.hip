@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
   if (total == 0) return;
   const bool stamp = a.stamps != nullptr && tid == 0;
   long long* st = a.stamps + (size_t)blockIdx.x * 16;
-  if (stamp) st[0] = (long long)__builtin_amdgcn_s_memtime();
+  if (stamp) { st[0] = (long long)__builtin_amdgcn_s_memtime(); st[14] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
   for (int i = 0; i < NST - 1; ++i)
     if (l_step < total) issue();
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
   if (stamp && c_ord < 2) st[2 + 2 * c_ord] = (long long)__builtin_amdgcn_s_memtime();
   epilogue();
   if (stamp && c_ord <= 2) st[1 + 2 * c_ord] = (long long)__builtin_amdgcn_s_memtime();
+  if (stamp) { st[13] = (long long)__builtin_amdgcn_s_memtime(); st[15] = (long long)__builtin_amdgcn_s_memrealtime(); }
 }
 
 template <int NSPLIT, int EPI>

@@ -926,6 +926,11 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
       pro += (double)(s[1] - s[0]); loop0 += (double)(s[2] - s[1]); epi0 += (double)(s[3] - s[2]); ++nb;
       if (s[4]) { loop1 += (double)(s[4] - s[3]); epi1 += (double)(s[5] - s[4]); ++nb1; }
     }
+    {
+      double clk = 0; int nc = 0;
+      for (int b = 0; b < 256; ++b) { const long long* s = &st[(size_t)b * 16]; if (s[0] && s[13] && s[15] > s[14]) { clk += (double)(s[13] - s[0]) / (double)(s[15] - s[14]) * 100.0; ++nc; } }
+      if (nc) fprintf(stderr, "[clock] in-kernel shader clock %.0f MHz (s_memtime / s_memrealtime, %d blocks)\n", clk / nc, nc);
+    }
     if (nb) fprintf(stderr, "[stamps] M=%d N=%d K=%d ns=%d epi=%d blocks=%d: prologue %.0f  loop0 %.0f  epi0 %.0f | loop1 %.0f epi1 %.0f (s_memtime ticks, nb1=%d)\n",
                     M, N, K, nsplit, epi, nb, pro / nb, loop0 / nb, epi0 / nb, nb1 ? loop1 / nb1 : 0.0, nb1 ? epi1 / nb1 : 0.0, nb1);
     if (a.ablate & 8) {

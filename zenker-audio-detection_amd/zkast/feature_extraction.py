@@ -36,7 +36,8 @@ class ZkASTFeatureExtractor:
     model_input_names = ["input_values", "attention_mask"]
 
     def __init__(self, feature_size=1, sampling_rate=16000, num_mel_bins=128, max_length=1024, padding_value=0.0,
-                 do_normalize=True, mean=-4.2677393, std=4.5689974, return_attention_mask=False, device=0, **kwargs):
+                 do_normalize=True, mean=-4.2677393, std=4.5689974, return_attention_mask=False, padding_side="right",
+                 device=0, **kwargs):
         if num_mel_bins != 128 or max_length != 1024 or sampling_rate != 16000:
             raise ValueError("ZkASTFeatureExtractor is specialised to sampling_rate=16000, num_mel_bins=128, "
                              "max_length=1024 (the AST configuration the reference trains and runs)")
@@ -49,6 +50,7 @@ class ZkASTFeatureExtractor:
         self.mean = mean
         self.std = std
         self.return_attention_mask = return_attention_mask
+        self.padding_side = padding_side
         self._device = device
         self._extra = {k: v for k, v in kwargs.items() if k not in ("feature_extractor_type", "processor_class")}
 
@@ -72,6 +74,7 @@ class ZkASTFeatureExtractor:
             "max_length": self.max_length,
             "mean": self.mean,
             "num_mel_bins": self.num_mel_bins,
+            "padding_side": self.padding_side,
             "padding_value": self.padding_value,
             "return_attention_mask": self.return_attention_mask,
             "sampling_rate": self.sampling_rate,
