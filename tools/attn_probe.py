@@ -1,0 +1,12 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "zenker-audio-detection_amd"))
+import numpy as np
+from zkast import lib
+ctx = lib.get_context(0)
+rng = np.random.default_rng(0)
+W = 32
+qkv = rng.normal(0, 1.0, (W * 1214, 2304)).astype(np.float32)
+for ns in (3, 1):
+    for _ in range(3):
+        ctx.test_attention(qkv, W, ns)
