@@ -185,6 +185,23 @@ def main():
         m1.set_compute_mode("f16x3")
         m2.set_compute_mode("f16x3")
 
+    # ---- BASELINE.json configs[1] as an extra line: batch 256, stage-1 only (log-mel + forward), both modes ----
+    if rank == 0 and world == 1:
+        def stage1_b256(reps=3):
+            n256 = min(256, B)
+            ctx.logmel(audio, n_samples, 0, hop, win, n256); ctx.ast_forward(0, None, None, n256, s1_logits)
+            barrier(); t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.logmel(audio, n_samples, 0, hop, win, n256)
+                ctx.ast_forward(0, None, None, n256, s1_logits)
+            barrier()
+            return n256 * reps / (time.perf_counter() - t0)
+        cfg1 = {"workload": "configs[1]: batch=256 windows, stage-1 only (log-mel + AST forward)", "unit": "windows/s"}
+        m1.set_compute_mode("f16x3"); cfg1["f16x3"] = stage1_b256()
+        m1.set_compute_mode("f16"); cfg1["f16"] = stage1_b256()
+        m1.set_compute_mode(args.mode)
+        out["config1_stage1_b256"] = cfg1
+
     # ---- CPU baseline: the oracle (numpy restatement) on this box's host cores, rank 0, N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import ast_oracle as orc
