@@ -227,3 +227,34 @@ def test_feature_cache_roundtrip_and_probs_from_features(tmp_path):
     pb = forward_probs(model, fx, wins, 4)
     assert np.array_equal(pa, pb)
     assert cache.forward_probs_from_features(model, f2[:0], 4).shape == (0, 0)
+
+
+@pytest.mark.parametrize("window_sec,hop_sec,n_samples", [(2.0, 1.0, 16000 * 5), (0.5, 0.25, 16000), (1.0, 0.5, 9000),
+                                                           (11.0, 11.0, 16000 * 11)])
+def test_other_window_geometries_vs_oracle(window_sec, hop_sec, n_samples):
+    """--window-sec / --hop-sec other than 1.0 / 0.5 (frames per window != 98; > 1024 frames truncates), and a recording
+    shorter than one window (zero-padded): fused recording path == oracle extractor + oracle model."""
+    from zkast import ZkASTFeatureExtractor, forward_probs_recording, synth
+    model, sd = _model(12, "init", 0)
+    fx = ZkASTFeatureExtractor(mean=-1.1509622, std=3.5340312)
+    rec = synth.synth_recording(33, n_samples)
+    p = forward_probs_recording(model, fx, rec, window_sec, hop_sec)
+    wins = orc.window_audio(rec, window_sec, hop_sec)
+    ref = orc.forward_probs(sd, -1.1509622, 3.5340312, wins[:3], 3)
+    assert p.shape == (len(wins), 2)
+    assert np.abs(p[:3] - ref).max() <= 2.5e-4
+
+
+def test_single_window_and_ragged_batches():
+    from zkast import lib, synth
+    model, sd = _model(12, "init", 0)
+    ctx = lib.get_context(0)
+    rec = synth.synth_recording(34, 16000 + 6 * 8000)
+    ctx.logmel(rec, rec.size, 0, 8000, 16000, 7)
+    all7 = model.forward_from_slot(7)
+    for mb in (1, 2, 3, 7, 0):
+        ctx.set_micro_batch(mb)
+        assert np.array_equal(model.forward_from_slot(7), all7), mb
+    ctx.set_micro_batch(0)
+    assert np.array_equal(model.forward_from_slot(1), all7[:1])
+    assert np.array_equal(model.forward_from_slot(0, np.zeros(0, np.int32)), np.zeros((0, 2), np.float32))
