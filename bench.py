@@ -208,6 +208,12 @@ def main():
         n_cpu = args.cpu_windows
         wins = orc.window_audio(rec[: win + (n_cpu - 1) * hop])
         W1, W2 = orc.ASTWeights(sd1), orc.ASTWeights(sd2)
+        try:                                    # report the BLAS threads actually used, not the box's core count
+            from threadpoolctl import threadpool_info
+            blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
+        except Exception:
+            blas_threads = None
+        allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
         t0 = time.perf_counter()
         f1 = orc.extract_features(wins, *S1)
         l1 = orc.ast_forward(f1, W1)
@@ -215,9 +221,11 @@ def main():
         l2 = orc.ast_forward(f2, W2)
         tc = time.perf_counter() - t0
         del f2
-        out["cpu_baseline"] = {"value": n_cpu / tc, "unit": "windows/s", "cores": os.cpu_count(), "kind": "port",
+        out["cpu_baseline"] = {"value": n_cpu / tc, "unit": "windows/s",
+                               "cores": blas_threads if blas_threads else allowed, "kind": "port",
                                "sample": f"{n_cpu} windows x (log-mel + AST) x 2 stages, numpy/BLAS fp32 oracle, "
-                                         f"{tc:.1f} s wall"}
+                                         f"{tc:.1f} s wall; BLAS threads {blas_threads}, cpus allowed {allowed}, "
+                                         f"os.cpu_count {os.cpu_count()} (log-mel part is single-threaded numpy)"}
         out["parity_in_bench"] = {"stage1_logit_max_abs_err_vs_oracle": None}
         # re-run the parity mode once so the comparison is against f16x3 logits
         ctx.logmel(audio, n_samples, 0, hop, win, B)

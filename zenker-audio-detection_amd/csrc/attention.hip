@@ -81,17 +81,39 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   // ---- K/V staging (global -> VGPR -> LDS) ----
   // 512 16-B chunks per image; thread handles chunks tid and tid+256: row = c>>3, col chunk = c&7
   h8_t pk[NIMG][2];
-  auto load_tile = [&](int kt) {
+  // per-lane byte offsets of this thread's two 16-B chunks inside a 64-key tile, computed once (the last tile clamps
+  // keys >= 1214 to 1213): a tile load is then 6 x global_load_dwordx4 v, v_off, s[base] with no vector address math
+  unsigned toff[2];
+  auto set_offs = [&](int kt) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int c = tid + u * 256;
       const int row = c >> 3, cc = c & 7;
       int key = kt * KT + row;
       key = key < S_ ? key : S_ - 1;
-      const size_t off = (tok0 + key) * QKV_LD + head * ZK_HEAD_DIM + cc * 8;
-      pk[0][u] = *(const h8_t*)(qkv_hi + off + ZK_HIDDEN);
-      if constexpr (SPLIT) pk[1][u] = *(const h8_t*)(qkv_lo + off + ZK_HIDDEN);
-      pk[NIMG - 1][u] = *(const h8_t*)(qkv_hi + off + 2 * ZK_HIDDEN);
+      toff[u] = (unsigned)(key - kt * KT) * (unsigned)(QKV_LD * 2) + (unsigned)(cc * 16);
+    }
+  };
+  set_offs(0);
+  auto uniform_ptr = [](const char* p) {
+    const unsigned long long g = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)g);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+  };
+  auto load_tile = [&](int kt) {
+    if (kt == NKT - 1) set_offs(kt);
+    const size_t tb = ((tok0 + (size_t)kt * KT) * QKV_LD + head * ZK_HEAD_DIM) * 2;     // bytes
+    const char* gk = uniform_ptr((const char*)qkv_hi + tb + ZK_HIDDEN * 2);
+    const char* gv = uniform_ptr((const char*)qkv_hi + tb + 2 * ZK_HIDDEN * 2);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pk[0][u] = *(const h8_t*)(gk + toff[u]);
+      if constexpr (SPLIT) {
+        const char* gl = uniform_ptr((const char*)qkv_lo + tb + ZK_HIDDEN * 2);
+        pk[1][u] = *(const h8_t*)(gl + toff[u]);
+      }
+      pk[NIMG - 1][u] = *(const h8_t*)(gv + toff[u]);
     }
   };
   auto store_tile = [&](int buf) {
