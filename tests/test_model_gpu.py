@@ -258,3 +258,28 @@ def test_single_window_and_ragged_batches():
     ctx.set_micro_batch(0)
     assert np.array_equal(model.forward_from_slot(1), all7[:1])
     assert np.array_equal(model.forward_from_slot(0, np.zeros(0, np.int32)), np.zeros((0, 2), np.float32))
+
+
+def test_error_behaviour_matches_contract():
+    """errors cross the C boundary as negative codes + message and surface as exceptions; no aborts, no silent fallback."""
+    from zkast import ZkASTConfig, ZkASTFeatureExtractor, ZkASTForAudioClassification, lib, synth
+    ctx = lib.get_context(0)
+    model, sd = _model(12, "init", 0)
+    with pytest.raises(ValueError, match="1024, 128"):
+        model(np.zeros((2, 100, 128), np.float32))
+    with pytest.raises(ValueError, match="shorter than one 25 ms frame"):
+        ZkASTFeatureExtractor()([np.zeros(100, np.float32)], sampling_rate=16000)
+    with pytest.raises(lib.ZkError, match="compute_mode"):
+        ctx._chk(ctx.lib.zk_model_set_compute_mode(ctx.h, 0, 7), "zk_model_set_compute_mode")
+    with pytest.raises(lib.ZkError, match="unsupported ASTConfig"):
+        ZkASTForAudioClassification(ZkASTConfig(hidden_size=512), sd, stage=1)
+    bad = {k: (v[:, :100] if k.endswith("fc1.weight") else v) for k, v in sd.items()}
+    with pytest.raises(lib.ZkError, match="elements, expected"):
+        ZkASTForAudioClassification(ZkASTConfig(), bad, stage=1)
+    with pytest.raises(lib.ZkError, match="stage must be 0 or 1"):
+        ctx.ast_forward(2, None, None, 1, np.zeros((1, 2), np.float32))
+    with pytest.raises(lib.ZkError, match="shorter than one 400-sample frame"):
+        ctx.logmel(np.zeros(1000, np.float32), 1000, 0, 100, 200, 1)
+    # a failed load leaves the slot unloaded and says so
+    with pytest.raises(lib.ZkError, match="no model loaded"):
+        ctx.ast_forward(1, None, None, 1, np.zeros((1, 2), np.float32))
