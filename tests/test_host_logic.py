@@ -205,3 +205,26 @@ def test_feature_cache_keys_match_reference(cases, tmp_path):
     meta = cache.build_base_metadata(str(wav), 1.0, 0.5, 1, 16000, fp)
     assert meta["audio_size"] == os.path.getsize(wav) and meta["extractor_fingerprint"] == fp
     assert cache.build_cache_path(str(tmp_path), str(wav), 1.0, 0.25, 16000, fp) != p1
+
+
+def test_prepare_long_audio_layout(tmp_path):
+    """utils/PrepareDatasetLongAudio.py: class/specimen/long-subfolder walk, Idle skipped, mono + native rate kept."""
+    import struct
+    from zkast import dataprep
+    raw, out = tmp_path / "raw", tmp_path / "Long"
+    x = (0.25 * np.sin(np.arange(4800) / 7.0)).astype(np.float32)
+    for cls, spec in [("Healthy", "224_m_60"), ("Zenker", "006_f_71"), ("Idle", "999_x")]:
+        d = raw / cls / spec / "Long_recordings"
+        d.mkdir(parents=True)
+        st2 = np.stack([x, 0.5 * x], 1).astype("<f4").tobytes()          # stereo float32 at 48 kHz
+        hdr = b"RIFF" + struct.pack("<I", 0) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 3, 2, 48000, 384000, 8, 32)
+        (d / "take1.WAV").write_bytes(hdr + b"data" + struct.pack("<I", len(st2)) + st2)
+        (raw / cls / spec / "short").mkdir()
+    (raw / "Zenker" / "007_nolong").mkdir()
+    logs = []
+    assert dataprep.prepare_long_audio(str(raw), str(out), log=logs.append) == 2
+    assert sorted(os.listdir(out)) == ["Healthy", "Zenker"] and os.listdir(out / "Healthy") == ["224"]
+    wav, sr = pl.read_wav(str(out / "Zenker" / "006" / "take1.wav"))
+    assert sr == 48000 and wav.shape == (1, 4800) and np.abs(wav[0] - 0.75 * x).max() <= 1.0 / 32768
+    assert any("No long file for specimen: 007_nolong" in str(l) for l in logs)
+    assert len(pl.window_audio(wav[0], 0.05, 0.05, 48000)) == 2
