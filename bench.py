@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step")
     ap.add_argument("--gate-rate", type=float, default=1.0, help="fraction of windows forced through stage 2")
     ap.add_argument("--micro-batch", type=int, default=0, help="0 = library default (auto)")
-    ap.add_argument("--mode", default="f16x3", choices=["f16x3", "f16"])
+    ap.add_argument("--mode", default="f16x3", choices=["f16x3", "f16c8", "f16"])
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary single-pass fp16 measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-windows", type=int, default=6)

@@ -88,6 +88,18 @@ def test_model_logits_and_checkpoints_vs_golden(G, tag, seed):
     lt = model(torch.from_numpy(feats)).logits
     assert tuple(lt.shape) == (4, 2) and lt.dtype == torch.float32
     assert np.array_equal(lt.numpy(), logits)
+    # fp16 + fp8-corrected mode: 2 matrix passes, same tolerance; hidden checkpoints too
+    model.set_compute_mode("f16c8")
+    ctx.debug_tap(11)
+    l8 = model(feats).logits
+    h = ctx.debug_get_tap(4)
+    ctx.debug_tap(-2)
+    ref_tok = g[f"{tag}_layer11_tok"]
+    assert np.abs(h[:, toks] - ref_tok).max() <= 2e-4 * np.abs(ref_tok).max()
+    err8 = np.abs(l8 - g[f"{tag}_logits"]).max()
+    print(f"[{tag}] f16c8 max-abs logit err vs transformers fp32: {err8:.3e}")
+    assert err8 <= TOL
+    assert np.abs(model(feats).logits - l8).max() == 0.0     # deterministic
     # single-pass fp16: faster, error stated (not the parity mode)
     model.set_compute_mode("f16")
     err1 = np.abs(model(feats).logits - g[f"{tag}_logits"]).max()

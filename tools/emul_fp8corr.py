@@ -1,0 +1,76 @@
+"""CPU emulation: logit error of candidate GEMM precision schemes vs fp32 (numpy oracle).  Experiment only."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, "oracle"); sys.path.insert(0, "zenker-audio-detection_amd")
+import ast_oracle as orc
+from zkast import synth
+
+def f16(x): return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+def fp8(x, kind="e4m3"):
+    t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    if kind == "e4m3":
+        return t.clamp(-448, 448).to(torch.float8_e4m3fn).float().numpy()
+    return t.clamp(-57344, 57344).to(torch.float8_e5m2).float().numpy()
+
+SCHEME = "x3"
+STAT = {}
+def lin(x, w, b, quant):
+    x = np.asarray(x, np.float32); w = np.asarray(w, np.float32)
+    xh = f16(x); xl = f16(x - xh); wh = f16(w); wl = f16(w - wh)
+    if SCHEME == "f32":
+        return x @ w.T + b
+    if SCHEME == "f16":
+        return xh @ wh.T + b
+    if SCHEME == "x3":
+        return xh @ wh.T + (xl @ wh.T + xh @ wl.T) + b
+    if SCHEME.startswith("fp8"):
+        kind = "e5m2" if "e5m2" in SCHEME else "e4m3"
+        # power-of-two scales: weights per tensor, activations fixed
+        wmax = np.abs(w).max(); a = np.floor(np.log2(224.0 / wmax))          # W*2^a max in [112,224]
+        c = 0.0 if "c0" in SCHEME else 2.0                                   # X*2^c
+        # lo parts: |Xl| <= 2^-11|X| ; scale so that Xl*2^d ~ X*2^c magnitudes: d = c+11
+        d = c + 11; bb = a + 11
+        x8 = fp8(x * 2.0**c, kind); xl8 = fp8((x - xh) * 2.0**d, kind)
+        w8 = fp8(w * 2.0**a, kind); wl8 = fp8((w - wh) * 2.0**bb, kind)
+        STAT["xsat"] = max(STAT.get("xsat", 0), float(np.abs(x * 2.0**c).max()))
+        corr = (xl8 @ w8.T + x8 @ wl8.T) * np.float32(2.0 ** -(a + d))
+        return xh @ wh.T + corr + b
+    raise ValueError
+def qk_pv_layer(h, L, quant=None):
+    # device arithmetic for attention: split QK^T (3 terms), single-pass f16 P.V
+    B, S, _ = h.shape
+    x = orc._ln(h, *L["ln1"])
+    sh = lambda t: t.reshape(B, S, orc.HEADS, orc.HEAD_DIM).transpose(0, 2, 1, 3)
+    q = sh(lin(x, *L["q"], None)) * np.float32(orc.HEAD_DIM ** -0.5); k = sh(lin(x, *L["k"], None)); v = sh(lin(x, *L["v"], None))
+    if SCHEME == "f32":
+        s = q @ k.transpose(0, 1, 3, 2)
+    else:
+        qh, kh = f16(q), f16(k); ql, kl = f16(q - qh), f16(k - kh)
+        s = qh @ kh.transpose(0, 1, 3, 2) + (ql @ kh.transpose(0, 1, 3, 2) + qh @ kl.transpose(0, 1, 3, 2))
+    s = s - s.max(-1, keepdims=True); e = np.exp(s)
+    if SCHEME == "f32":
+        a = (e / e.sum(-1, keepdims=True)) @ v
+    else:
+        a = (f16(e) @ f16(v)) / e.sum(-1, keepdims=True)
+    a = a.transpose(0, 2, 1, 3).reshape(B, S, orc.HIDDEN)
+    h = h + lin(a, *L["o"], None)
+    x = orc._ln(h, *L["ln2"])
+    m = orc._gelu(lin(x, *L["fc1"], None))
+    return (h + lin(m, *L["fc2"], None)).astype(np.float32)
+
+def main():
+    global SCHEME
+    wset, seed = sys.argv[1], int(sys.argv[2])
+    schemes = sys.argv[3:]
+    sd = synth.make_ast_weights(seed, wset)
+    feats = orc.extract_features(synth.golden_windows()[[0, 1, 2, 4]], -4.2677393, 4.5689974)
+    ref = orc.ast_forward(feats, sd)
+    print("ref logits", ref.ravel())
+    orc.encoder_layer = qk_pv_layer
+    real_lin = orc._lin
+    for s in schemes:
+        SCHEME = s; STAT.clear()
+        orc._lin = (lambda x, w, b, q: real_lin(x, w, b, None)) if s == "f32" else lin
+        t = time.time(); out = orc.ast_forward(feats, sd)
+        print(f"{s:12s} max|dlogit| = {np.abs(out - ref).max():.3e}  rms {np.sqrt(((out-ref)**2).mean()):.3e}  xmax {STAT.get('xsat',0):.1f}  ({time.time()-t:.0f}s)", flush=True)
+main()

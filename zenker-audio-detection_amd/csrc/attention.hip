@@ -31,7 +31,7 @@ constexpr int TILE_B = KT * 128;        // bytes of one [64][64] fp16 image
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict__ qkv_hi,
                                                         const half_t* __restrict__ qkv_lo, half_t* __restrict__ o_hi,
-                                                        half_t* __restrict__ o_lo, int n_windows, int q_tiles) {
+                                                        half_t* __restrict__ o_lo, int n_windows, int q_tiles, int lo_fmt) {
   constexpr bool SPLIT = (NSPLIT == 3);
   constexpr int NIMG = SPLIT ? 3 : 2;     // Kh, [Kl], V
   constexpr int BUF_B = NIMG * TILE_B;
@@ -250,15 +250,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int d = 32 * mb + 8 * rg + 4 * half;
-        h4_t hi, lo;
+        h4_t hi;
+        float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float v = oacc[mb][4 * rg + j] * inv;
-          hi[j] = (half_t)v;
-          lo[j] = (half_t)(v - (float)hi[j]);
+          v[j] = oacc[mb][4 * rg + j] * inv;
+          hi[j] = (half_t)v[j];
         }
         *(h4_t*)(o_hi + obase + d) = hi;
-        if (o_lo) *(h4_t*)(o_lo + obase + d) = lo;
+        if (o_lo) *(h4_t*)(o_lo + obase + d) = zk_lo4(v, hi, lo_fmt);
       }
   }
 }
@@ -271,9 +271,9 @@ void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit
   const int grid = q_tiles * ZK_HEADS * n_windows;
   if (nsplit == 3) {
     hipLaunchKernelGGL(attention_kernel<3>, dim3(grid), dim3(256), 2 * 3 * TILE_B, s, qkv.hi, qkv.lo, out.hi, out.lo,
-                       n_windows, q_tiles);
+                       n_windows, q_tiles, out.lo_fmt);
   } else {
     hipLaunchKernelGGL(attention_kernel<1>, dim3(grid), dim3(256), 2 * 2 * TILE_B, s, qkv.hi, qkv.lo, out.hi, out.lo,
-                       n_windows, q_tiles);
+                       n_windows, q_tiles, out.lo_fmt);
   }
 }

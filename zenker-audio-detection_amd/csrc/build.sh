@@ -10,8 +10,8 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # them in AGPRs and the attention softmax pays ~150 v_accvgpr_read/write per key tile.
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
 pids=()
-for f in gemm attention layernorm embed head logmel misc zkast; do
-  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/zk_common.h" -nt "$OBJ/$f.o" ] \
+for f in gemm gemm_c8 attention layernorm embed head logmel misc zkast; do
+  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/zk_common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/gemm_util.h" -nt "$OBJ/$f.o" ] \
      || [ "$HERE/../../include/zkast.h" -nt "$OBJ/$f.o" ]; then
     EXTRA=""
     # attention: scores are finite by construction (masking uses -1e30, not -inf), so fmax needs no sNaN-quieting
@@ -22,5 +22,5 @@ for f in gemm attention layernorm embed head logmel misc zkast; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libzkast.so" "$OBJ"/{gemm,attention,layernorm,embed,head,logmel,misc,zkast}.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libzkast.so" "$OBJ"/{gemm,gemm_c8,attention,layernorm,embed,head,logmel,misc,zkast}.o
 echo "built $OUT/libzkast.so"

@@ -17,7 +17,7 @@ namespace {
 template <bool COMPACT>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ src, int n_frames,
                                                      const int32_t* __restrict__ win_idx, int n_windows, float mean,
-                                                     float std2, half_t* __restrict__ o_hi, half_t* __restrict__ o_lo) {
+                                                     float std2, half_t* __restrict__ o_hi, half_t* __restrict__ o_lo, int lo_fmt) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)n_windows * ZK_NPATCH * 32;
   if (gid >= total) return;
@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ s
   const int mel = f * ZK_FSTRIDE + kf;
   const int time0 = t * ZK_TSTRIDE + kt0;
   const int w = COMPACT ? (win_idx ? win_idx[b] : b) : b;
-  h8_t hi, lo;
+  h8_t hi;
+  float vv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int time = time0 + j;
@@ -42,10 +43,13 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ s
       v = src[((size_t)w * ZK_MAXLEN + time) * ZK_NMEL + mel];
     }
     hi[j] = (half_t)v;
-    lo[j] = (half_t)(v - (float)hi[j]);
+    vv[j] = v;
   }
   *(h8_t*)(o_hi + prow * ZK_PATCH_K + seg * 8) = hi;
-  if (o_lo) *(h8_t*)(o_lo + prow * ZK_PATCH_K + seg * 8) = lo;
+  if (o_lo) {
+    *(h4_t*)(o_lo + prow * ZK_PATCH_K + seg * 8) = zk_lo4(vv, __builtin_shufflevector(hi, hi, 0, 1, 2, 3), lo_fmt);
+    *(h4_t*)(o_lo + prow * ZK_PATCH_K + seg * 8 + 4) = zk_lo4(vv + 4, __builtin_shufflevector(hi, hi, 4, 5, 6, 7), lo_fmt);
+  }
 }
 
 __global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ hidden, const float* __restrict__ cls,
@@ -91,14 +95,14 @@ void zk_launch_im2col_compact(const float* feats, int n_frames, const int32_t* w
   if (n_windows <= 0) return;
   const int64_t total = (int64_t)n_windows * ZK_NPATCH * 32;
   hipLaunchKernelGGL(im2col_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feats, n_frames,
-                     win_idx, n_windows, mean, std2, out.hi, out.lo);
+                     win_idx, n_windows, mean, std2, out.hi, out.lo, out.lo_fmt);
 }
 
 void zk_launch_im2col_full(const float* input_values, int n_windows, zk_planes out, hipStream_t s) {
   if (n_windows <= 0) return;
   const int64_t total = (int64_t)n_windows * ZK_NPATCH * 32;
   hipLaunchKernelGGL(im2col_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, input_values,
-                     ZK_MAXLEN, (const int32_t*)nullptr, n_windows, 0.f, 1.f, out.hi, out.lo);
+                     ZK_MAXLEN, (const int32_t*)nullptr, n_windows, 0.f, 1.f, out.hi, out.lo, out.lo_fmt);
 }
 
 void zk_launch_cls_rows(float* hidden, const float* cls, const float* dist, const float* pos, int n_windows,

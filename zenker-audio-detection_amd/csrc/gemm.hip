@@ -19,39 +19,9 @@
 //    needs no VGPR-destination global load, which would make hipcc drain the ring with vmcnt(0).
 //  * NSPLIT=3: every operand is an (hi, lo) fp16 pair, acc += Wl·Xh + Wh·Xl + Wh·Xh  (fp32-equivalent product,
 //    2^-22 relative) — the mode that meets the 1e-3 logit tolerance; NSPLIT=1 is the plain fp16 pass.
-#include "zk_common.h"
+#include "gemm_util.h"
 
 namespace {
-
-__device__ __forceinline__ float gelu_erf(float x) {
-  // 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7), exact-erf GELU as
-  // $TF/activations.py:70-89 to well below the fp32 noise of the surrounding GEMMs.
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __expf(-z * z);
-  const float erf_abs = fmaf(-p, e, 1.0f);
-  const float erf_v = copysignf(erf_abs, x);
-  return 0.5f * x * (1.0f + erf_v);
-}
-
-// make wave-uniformity of a pointer provable to the compiler, so that  ptr + zext(u32 lane offset)  selects the
-// SGPR-base + VGPR-offset addressing mode
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {
-  const unsigned long long g = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)g);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
-  return (const char*)(((unsigned long long)hi << 32) | lo);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <int NSPLIT, int BM, int BN, int BK, int WM, int WN, int NST, int EPI>
 __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
@@ -237,8 +207,11 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
 #pragma unroll
         for (int j = 0; j < RM; ++j) {
           const int m = m0 + j * 16 + frow, n = n0 + i * 16 + 4 * fq;
-          const f4_t v = acc[i][j] + b4[i];
+          f4_t v = acc[i][j] + b4[i];
           acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+          // pin v in front of the divergent tail guard: hipcc otherwise sinks the MFMA that produces acc[i][j] into
+          // the guarded block, where it would run with a partial EXEC mask (wrong A/B rows from the masked lanes)
+          asm volatile("" : "+v"(v));
           if (m >= a.M) continue;
           const int b = m / ZK_NPATCH, p = m - b * ZK_NPATCH;
           const f4_t pe = *(const f4_t*)(a.pos + (size_t)(p + 2) * a.N + n);

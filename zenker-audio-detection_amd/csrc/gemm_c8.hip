@@ -1,0 +1,372 @@
+// MFMA GEMM, "fp16 + fp8-corrected" mode (ZK_F16C8):  out[M,N] = X[M,K] · W[N,K]^T + bias  (+ fused epilogue)
+//
+// Same role as gemm.hip (every nn.Linear of ASTAttention / ASTMLP and the patch-embedding Conv2d-as-GEMM,
+// $TF/models/audio_spectrogram_transformer/modeling_audio_spectrogram_transformer.py:57-61,140-143,174,187-192) and the
+// same fp32-grade product, at 2 matrix-pipe passes instead of 3:
+//
+//     X·W = Xh·Wh + (Xl·W + X·Wl) + O(2^-22),        Xh = fp16(X), Xl = X - Xh  (|Xl| <= 2^-11 |X|), same for W.
+//
+// The bracket is 2^-11 of the result, so 4 significant bits are plenty for it.  Each operand therefore carries, next
+// to its fp16 plane, a "c8" plane of byte pairs  X' = (fp8(Xl·2^11), fp8(X)),  W' = (fp8(W·2^e), fp8(Wl·2^(e+11)))
+// (OCP e4m3).  Read as rows of 2K bytes, X'·W'^T IS the bracket times 2^(e+11): one fp8 GEMM with K' = 2K on
+// v_mfma_scale_f32_16x16x128_f8f6f4, whose A-side block scale 2^-(e+11) puts it straight into the accumulator of
+// the fp16 product (2x the fp16 rate -> the K' = 2K product costs one fp16 pass).
+//
+// gfx950 structure (differences to gemm.hip):
+//  * a ring step is 64 k-elements = 128-byte rows for BOTH plane kinds (fp16: 64 x 2 B, c8: 64 x 2 B), 64 KiB per
+//    step, two ring slots.  Steps alternate  main(k) -> slot 0,  corr(k) -> slot 1,  so slot, plane and MFMA kind of
+//    a step are compile-time constants of a 2x-unrolled loop.
+//  * a lane's fragment of a 16-row tile is 32 bytes of its row: 16-B chunks q and q+4 (q = lane>>4) of the
+//    XOR-swizzled row image (conflict-free ds_read_b128 pair).  Both operands use the same K permutation, which is
+//    all an MFMA needs; the fp16 step feeds the two halves to two 16x16x32 MFMAs, the fp8 step feeds all 8 VGPRs
+//    to one 16x16x128 MFMA.
+//  * W-stationary: the 4 W fragments of the wave's 64 columns stay in registers for the whole step, the 8 X
+//    fragments stream through a 2-deep register buffer (24 ds_read_b128 per step and wave).  The last X tile of a
+//    step is multiplied AFTER the step's barrier, behind the first fragment reads of the next step.
+#include <type_traits>
+
+#include "gemm_util.h"
+
+namespace {
+
+typedef int i4v_t __attribute__((ext_vector_type(4)));
+typedef int i8v_t __attribute__((ext_vector_type(8)));
+struct frag_t { i4v_t a, b; };
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
+  constexpr int BM = 256, BN = 256, BK = 64, WM = 2, WN = 4;
+  constexpr int ROWB = 128, CPR = 8, RPI = 8;
+  constexpr int TM = BM / WM, TN = BN / WN;       // 128 x 64 per wave
+  constexpr int RM = TM / 16, RN = TN / 16;       // 8 X tiles, 4 W tiles
+  constexpr int XBYTES = BM * ROWB, WBYTES = BN * ROWB, STAGE = XBYTES + WBYTES;
+  constexpr int XI = BM / RPI / 8, WI = BN / RPI / 8, LPT = XI + WI;   // 1-KiB LDS-DMA pieces per wave and step
+  constexpr int BIAS_OFF = 2 * STAGE;
+  constexpr int SCR_OFF = BIAS_OFF + 2 * 8 * 256;
+  constexpr int SCR_STR = 144, SCR_WAVE = 16 * SCR_STR;
+  constexpr int TILE_B = 16 * ROWB;               // 2048 B between consecutive 16-row tiles
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_n = a.N / BN;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = a.K / BK;
+  const int per = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int first = xcd * per + jb;
+  const int stride = 8 * per;
+  const int my_tiles = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+  const int total = my_tiles * nk * 2;
+  if (total == 0) return;
+
+  // ---- staging ----
+  const int srow = lane / CPR, schunk = lane % CPR;
+  int l_step = 0, l_k = 0, l_ord = 0, l_tile = first;
+  int l_m0 = (first / tiles_n) * BM, l_n0 = (first % tiles_n) * BN;
+  unsigned xoffs[XI], woffs[WI];
+  auto set_xoffs = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < XI; ++q) {
+      const int row = (q * 8 + wave) * RPI + srow;
+      int grow = l_m0 + row;
+      grow = grow < a.M ? grow : a.M - 1;
+      const int c = schunk ^ ((row >> 1) & (CPR - 1));
+      xoffs[q] = (unsigned)(grow - l_m0) * (unsigned)(a.K * 2) + (unsigned)(c * 16);
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < WI; ++q) {
+    const int row = (q * 8 + wave) * RPI + srow;
+    const int c = schunk ^ ((row >> 1) & (CPR - 1));
+    woffs[q] = (unsigned)row * (unsigned)(a.K * 2) + (unsigned)(c * 16);
+  }
+  set_xoffs();
+  // piece `pc` of the step at the load cursor; KIND (0 = fp16 planes -> slot 0, 1 = c8 planes -> slot 1) is static.
+  // Pieces are UNCONDITIONAL so that a ring step is one basic block (hipcc otherwise sinks the MFMAs of a step below
+  // all of its memory instructions): once the cursor has run past the last step it stays on it and the pieces
+  // re-fetch that step into the slot nobody reads any more.
+  auto issue_piece = [&](auto kind_c, int pc) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    char* base = smem + KIND * STAGE;
+    const half_t* xpl = KIND ? a.x_lo : a.x_hi;
+    const half_t* wpl = KIND ? a.w_lo : a.w_hi;
+    const int k0 = l_k * BK;
+    if (pc < XI) {
+      const int instr = pc * 8 + wave;
+      const char* gb = uniform_ptr((const char*)(xpl + (size_t)l_m0 * a.K + k0));
+      asm volatile("" : "+v"(xoffs[pc]));      // keep the offset a 32-bit VGPR: SGPR-base + voffset addressing
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + xoffs[pc]),
+                                       (__attribute__((address_space(3))) void*)(base + instr * 1024), 16, 0, 0);
+    } else {
+      const int instr = (pc - XI) * 8 + wave;
+      const char* gb = uniform_ptr((const char*)(wpl + (size_t)l_n0 * a.K + k0));
+      asm volatile("" : "+v"(woffs[pc - XI]));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + woffs[pc - XI]),
+                                       (__attribute__((address_space(3))) void*)(base + XBYTES + instr * 1024), 16, 0,
+                                       0);
+    }
+    if (KIND == 0 && pc == 0) {      // the tile's bias slice rides along with every fp16 step (256 B per wave)
+      const float* src = a.bias + l_n0 + wn * TN + lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + BIAS_OFF +
+                                                                                 ((l_ord & 1) * 8 + wave) * 256),
+                                       4, 0, 0);
+    }
+  };
+  auto advance_load = [&](auto kind_c) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    ++l_step;
+    if (KIND == 1 && l_step < total) {      // past the end the cursor stays on the last step (see issue_piece)
+      if (++l_k == nk) {
+        l_k = 0; ++l_ord; l_tile += stride;
+        const int tm = l_tile / tiles_n;
+        l_m0 = tm * BM; l_n0 = (l_tile - tm * tiles_n) * BN;
+        set_xoffs();
+      }
+    }
+  };
+
+  f4_t acc[RN][RM];
+#pragma unroll
+  for (int i = 0; i < RN; ++i)
+#pragma unroll
+    for (int j = 0; j < RM; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: row = tile_base + (lane&15), chunks q and q+4 of the swizzled row
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  const int fsw = (lane >> 1) & 7;
+  const int xoff = (wm * TM + frow) * ROWB + ((fq ^ fsw) & 7) * 16;
+  const int woff = XBYTES + (wn * TN + frow) * ROWB + ((fq ^ fsw) & 7) * 16;
+  auto ld_frag = [&](const char* slot, int off, int tile) __attribute__((always_inline)) -> frag_t {
+    frag_t f;
+    f.a = *(const i4v_t*)(slot + off + tile * TILE_B);
+    f.b = *(const i4v_t*)(slot + (off ^ 64) + tile * TILE_B);
+    return f;
+  };
+  // e8m0 block scales of the fp8 MFMA: W' side 2^-(w_exp + 11), X' side 1
+  const int sc_w = (127 - (a.w_exp + ZK_C8_SHIFT)) * 0x01010101;
+  const int sc_x = 0x7f7f7f7f;
+  // HALF: fp16 kind: 0 / 1 = first / second 32-deep MFMA of the 64-deep step (issued as two sweeps over the W tiles, so
+  // consecutive MFMAs never depend on each other); fp8 kind: one 128-byte-deep MFMA (HALF 0 only)
+  auto mma = [&](auto kind_c, auto half_c, f4_t& c, const frag_t& w, const frag_t& x) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    constexpr int HALF = decltype(half_c)::value;
+    if constexpr (KIND == 0) {
+      if constexpr (HALF == 0)
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, w.a), __builtin_bit_cast(h8_t, x.a), c, 0, 0, 0);
+      else
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, w.b), __builtin_bit_cast(h8_t, x.b), c, 0, 0, 0);
+    } else if constexpr (HALF == 0) {
+      const i8v_t wv = __builtin_shufflevector(w.a, w.b, 0, 1, 2, 3, 4, 5, 6, 7);
+      const i8v_t xv = __builtin_shufflevector(x.a, x.b, 0, 1, 2, 3, 4, 5, 6, 7);
+      c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, xv, c, 0, 0, 0, sc_w, 0, sc_x);
+    }
+  };
+
+  frag_t wf[RN];      // W tiles of the current step
+  frag_t xf[2];       // X tile j lives in xf[j & 1]
+
+  int c_ord = 0, c_tile = first;
+  // ---- epilogue (accumulator layout and LDS-transposed stores as in gemm.hip) ----
+  char* scr = smem + SCR_OFF + wave * SCR_WAVE;
+  const int rd_row = lane >> 3, rd_ch = lane & 7;
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const int tm = c_tile / tiles_n, tn = c_tile - tm * tiles_n;
+    const int m0 = tm * BM + wm * TM, n0 = tn * BN + wn * TN;
+    const char* bslot = smem + BIAS_OFF + ((c_ord & 1) * 8 + wave) * 256;
+    f4_t b4[RN];
+#pragma unroll
+    for (int i = 0; i < RN; ++i) b4[i] = *(const f4_t*)(bslot + (i * 16 + 4 * fq) * 4);
+    if constexpr (EPI == ZK_EPI_PATCH) {
+#pragma unroll
+      for (int i = 0; i < RN; ++i)
+#pragma unroll
+        for (int j = 0; j < RM; ++j) {
+          const int m = m0 + j * 16 + frow, n = n0 + i * 16 + 4 * fq;
+          f4_t v = acc[i][j] + b4[i];
+          acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+          // pin v in front of the divergent tail guard: hipcc otherwise sinks the MFMA that produces acc[i][j] into
+          // the guarded block, where it would run with a partial EXEC mask (wrong A/B rows from the masked lanes)
+          asm volatile("" : "+v"(v));
+          if (m >= a.M) continue;
+          const int b = m / ZK_NPATCH, p = m - b * ZK_NPATCH;
+          const f4_t pe = *(const f4_t*)(a.pos + (size_t)(p + 2) * a.N + n);
+          *(f4_t*)(a.resid + ((size_t)b * ZK_SEQ + 2 + p) * a.N + n) = v + pe;
+        }
+    } else if constexpr (EPI == ZK_EPI_RESID) {
+#pragma unroll
+      for (int j = 0; j < RM; ++j)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+          for (int il = 0; il < 2; ++il) {
+            *(f4_t*)(scr + frow * SCR_STR + il * 64 + fq * 16) = acc[hf * 2 + il][j] + b4[hf * 2 + il];
+            acc[hf * 2 + il][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const f4_t v = *(const f4_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+            const int m = m0 + j * 16 + rd_row + 8 * t;
+            if (m < a.M) {
+              float* dst = a.resid + (size_t)m * a.N + n0 + hf * 32 + rd_ch * 4;
+              *(f4_t*)dst = *(const f4_t*)dst + v;
+            }
+          }
+        }
+    } else {
+      // STORE (fused QKV): the lo plane stays fp16 — q and k feed the split QK^T of attention.hip.
+      // GELU (FC1 -> FC2 operand): the lo plane is the c8 byte pair.
+      constexpr int LOFMT = (EPI == ZK_EPI_GELU) ? ZK_LO_C8 : ZK_LO_F16;
+      const bool want_lo = a.o_lo != nullptr && n0 < a.lo_n_limit;
+#pragma unroll
+      for (int j = 0; j < RM; ++j) {
+        h4_t lo4[RN];
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+          f4_t v = acc[i][j] + b4[i];
+          acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+          if constexpr (EPI == ZK_EPI_GELU) {
+            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+          }
+          h4_t hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hi[e] = (half_t)v[e];
+          const float vv[4] = {v[0], v[1], v[2], v[3]};
+          lo4[i] = zk_lo4(vv, hi, LOFMT);
+          *(h4_t*)(scr + frow * SCR_STR + i * 32 + fq * 8) = hi;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+          const int m = m0 + j * 16 + rd_row + 8 * t;
+          if (m < a.M) *(h8_t*)(a.o_hi + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+        }
+        if (want_lo) {
+#pragma unroll
+          for (int i = 0; i < RN; ++i) *(h4_t*)(scr + frow * SCR_STR + i * 32 + fq * 8) = lo4[i];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+            const int m = m0 + j * 16 + rd_row + 8 * t;
+            if (m < a.M) *(h8_t*)(a.o_lo + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+          }
+        }
+      }
+    }
+    ++c_ord; c_tile += stride;
+  };
+
+  const bool stamp = a.stamps != nullptr && tid == 0;
+  long long* st = a.stamps + (size_t)blockIdx.x * 16;
+  if (stamp) { st[0] = (long long)__builtin_amdgcn_s_memtime(); st[14] = (long long)__builtin_amdgcn_s_memrealtime(); }
+
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using H0 = K0;
+  using H1 = K1;
+
+  // prologue: step 0 (main, slot 0) lands before anything is read
+#pragma unroll
+  for (int pc = 0; pc < LPT; ++pc) issue_piece(K0{}, pc);
+  advance_load(K0{});
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (stamp) st[1] = (long long)__builtin_amdgcn_s_memtime();
+
+  int c_k = 0;
+  bool epi_pending = false;
+
+  // one ring step of kind KIND (its slot), prefetching the following step (kind KIND^1) into the other slot
+  auto step = [&](auto kind_c) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    using KN = std::integral_constant<int, KIND ^ 1>;
+    const char* slot = smem + KIND * STAGE;
+    // X tile 0 of this step, then per W tile i: the deferred MFMA of the previous step (old wf[i], X tile RM-1 in
+    // xf[1]) followed by the read of this step's W fragment INTO wf[i] — one W register set serves both steps
+    xf[0] = ld_frag(slot, xoff, 0);
+#pragma unroll
+    for (int i = 0; i < RN; ++i) {
+      mma(KN{}, H0{}, acc[i][RM - 1], wf[i], xf[1]);      // (very first step: zero fragments)
+      mma(KN{}, H1{}, acc[i][RM - 1], wf[i], xf[1]);
+      wf[i] = ld_frag(slot, woff, i);
+    }
+    if constexpr (KIND == 0) {
+      if (epi_pending) {
+        epilogue();
+        epi_pending = false;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // chunks j = 0 .. RM-2: read X tile j+1 first (pinned in front of the MFMAs, consumed one chunk later), then the
+    // MFMAs of tile j with the 8 LDS-DMA pieces of the next step spread over chunks 0 and 1 (one per 32 MFMA cycles)
+#pragma unroll
+    for (int j = 0; j < RM - 1; ++j) {
+      xf[(j + 1) & 1] = ld_frag(slot, xoff, j + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < RN; ++i) {
+        if (j < 2 && (KIND == 1 || (i & 1) == 0)) issue_piece(KN{}, j * 4 + (KIND == 1 ? i : i / 2));
+        mma(kind_c, H0{}, acc[i][j], wf[i], xf[j & 1]);
+      }
+      if constexpr (KIND == 0) {
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+          if (j < 2 && (i & 1) == 0) issue_piece(KN{}, j * 4 + 2 + i / 2);
+          mma(kind_c, H1{}, acc[i][j], wf[i], xf[j & 1]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    advance_load(KN{});
+    if (KIND == 1) {
+      if (++c_k == nk) { c_k = 0; epi_pending = true; }
+    }
+    // the next step must have landed; X tile RM-1 of this step (xf[1]) and wf[] are in registers
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+#pragma unroll
+  for (int i = 0; i < RN; ++i) wf[i].a = wf[i].b = i4v_t{0, 0, 0, 0};
+  xf[1].a = xf[1].b = i4v_t{0, 0, 0, 0};
+  for (int c_step = 0; c_step < total; c_step += 2) {
+    step(K0{});
+    step(K1{});
+  }
+  // deferred tile of the last step (kind 1)
+#pragma unroll
+  for (int i = 0; i < RN; ++i) mma(K1{}, H0{}, acc[i][RM - 1], wf[i], xf[1]);
+  epilogue();
+  if (stamp) { st[13] = (long long)__builtin_amdgcn_s_memtime(); st[15] = (long long)__builtin_amdgcn_s_memrealtime(); }
+}
+
+template <int EPI>
+void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
+  constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144;
+  auto k = gemm_c8_kernel<EPI>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  const int ntiles = ((a.M + 255) / 256) * (a.N / 256);
+  const int grid = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
+}
+
+}  // namespace
+
+// Host-side shape contract as zk_launch_gemm: N % 256 == 0, K % 64 == 0, M >= 1; x_lo / w_lo are c8 planes.
+void zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s) {
+  switch (epi) {
+    case ZK_EPI_STORE: launch_cfg<ZK_EPI_STORE>(a, s); break;
+    case ZK_EPI_GELU: launch_cfg<ZK_EPI_GELU>(a, s); break;
+    case ZK_EPI_RESID: launch_cfg<ZK_EPI_RESID>(a, s); break;
+    default: launch_cfg<ZK_EPI_PATCH>(a, s); break;
+  }
+}

@@ -15,7 +15,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t row_stride,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int rows, half_t* o_hi,
-                                                        half_t* o_lo, float eps) {
+                                                        half_t* o_lo, int lo_fmt, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -42,15 +42,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int c = i * 256 + lane * 4;
     const f4_t g = *(const f4_t*)(gamma + c);
     const f4_t b = *(const f4_t*)(beta + c);
-    h4_t hi, lo;
+    h4_t hi;
+    float y[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float y = fmaf((v[i][j] - mean) * rstd, g[j], b[j]);
-      hi[j] = (half_t)y;
-      lo[j] = (half_t)(y - (float)hi[j]);
+      y[j] = fmaf((v[i][j] - mean) * rstd, g[j], b[j]);
+      hi[j] = (half_t)y[j];
     }
     *(h4_t*)(o_hi + (size_t)row * ZK_HIDDEN + c) = hi;
-    if (o_lo) *(h4_t*)(o_lo + (size_t)row * ZK_HIDDEN + c) = lo;
+    if (o_lo) *(h4_t*)(o_lo + (size_t)row * ZK_HIDDEN + c) = zk_lo4(y, hi, lo_fmt);
   }
 }
 
@@ -60,5 +60,5 @@ void zk_launch_layernorm(const float* x, int64_t row_stride, const float* gamma,
                          zk_planes out, float eps, hipStream_t s) {
   if (rows <= 0) return;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, gamma, beta, rows,
-                     out.hi, out.lo, eps);
+                     out.hi, out.lo, out.lo_fmt, eps);
 }

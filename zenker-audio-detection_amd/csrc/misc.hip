@@ -29,6 +29,20 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
   }
 }
 
+// fp32 -> c8 plane (16 bits per element, see zk_common.h).  Weights: (fp8(w·2^e), fp8((w - fp16(w))·2^(e+11)));
+// activations: (fp8((x - fp16(x))·2^11), fp8(x)).  Element i of the c8 plane meets element i of the other operand's
+// c8 plane in the fp8 MFMA, so byte 0 of one side always multiplies byte 0 of the other: w8·xl8 + wl8·x8.
+__global__ __launch_bounds__(256) void split_c8_kernel(const float* __restrict__ src, int64_t n, float s_main,
+                                                       float s_lo, int is_weight, unsigned short* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = src[i];
+  const float l = x - (float)(half_t)x;
+  const float b0 = is_weight ? x * s_main : l * s_lo;
+  const float b1 = is_weight ? l * s_lo : x * s_main;
+  out[i] = (unsigned short)__builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8(b0), zk_clamp_fp8(b1), 0, false);
+}
+
 // out[i*neu + p] = sum_j kernels[p][j] * padded[i*orig + j],  padded = zeros(width) ++ in ++ zeros(width+orig)
 // (torchaudio.functional._apply_sinc_resample_kernel: conv1d with stride=orig over the padded waveform).
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, int64_t n_in, int orig, int neu,
@@ -62,4 +76,12 @@ void zk_launch_resample(const float* in, int64_t n_in, int orig, int neu, int wi
   if (n_out <= 0) return;
   hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, in, n_in, orig, neu,
                      width, kernels, klen, out, n_out);
+}
+
+void zk_launch_split_c8(const float* src, int64_t n, int w_exp, int is_weight, half_t* c8, hipStream_t s) {
+  if (n <= 0) return;
+  const float s_main = is_weight ? ldexpf(1.0f, w_exp) : 1.0f;
+  const float s_lo = ldexpf(1.0f, (is_weight ? w_exp : 0) + ZK_C8_SHIFT);
+  hipLaunchKernelGGL(split_c8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, n, s_main, s_lo, is_weight,
+                     (unsigned short*)c8);
 }

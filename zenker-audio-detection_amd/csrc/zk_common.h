@@ -35,11 +35,39 @@ typedef short s4v_t __attribute__((__vector_size__(4 * sizeof(short))));
 #define ZK_FFT 512
 #define ZK_NBINS 257
 
-// activation planes: a tensor is stored as one (hi) or two (hi, lo) fp16 planes; x ~= hi + lo
+// activation planes: a tensor is stored as one (hi) or two (hi, lo) 16-bit planes.
+//   lo_fmt ZK_LO_F16: lo = fp16(x - hi), x ~= hi + lo                      (ZK_F16X3 GEMMs, split QK^T)
+//   lo_fmt ZK_LO_C8 : lo = (fp8 e4m3 of (x - hi)·2^11, fp8 e4m3 of x) byte pair   (ZK_F16C8 GEMMs: the two correction
+//                     products of the split run on the fp8 matrix pipe as ONE K'=2K product, see gemm_c8.hip)
+enum { ZK_LO_F16 = 0, ZK_LO_C8 = 1 };
 struct zk_planes {
   half_t* hi;
   half_t* lo;  // nullptr in single-pass mode
+  int lo_fmt;
 };
+
+#define ZK_C8_SHIFT 11   // (x - hi) is scaled by 2^11 before the fp8 rounding: |x - hi| <= 2^-11 |x|
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float zk_clamp_fp8(float x) { return __builtin_fminf(__builtin_fmaxf(x, -448.f), 448.f); }
+// two consecutive elements (value v, its fp16 rounding h) -> one dword of two (lo8, x8) byte pairs (OCP e4m3, RNE)
+__device__ __forceinline__ unsigned zk_c8_pack2(float v0, float h0, float v1, float h1) {
+  int p = __builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8((v0 - h0) * 2048.f), zk_clamp_fp8(v0), 0, false);
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8((v1 - h1) * 2048.f), zk_clamp_fp8(v1), p, true);
+  return (unsigned)p;
+}
+// lo plane entries of 4 consecutive elements in either format
+__device__ __forceinline__ h4_t zk_lo4(const float* v, h4_t hi, int fmt) {
+  if (fmt == ZK_LO_C8) {
+    unsigned d[2] = {zk_c8_pack2(v[0], (float)hi[0], v[1], (float)hi[1]), zk_c8_pack2(v[2], (float)hi[2], v[3], (float)hi[3])};
+    return __builtin_bit_cast(h4_t, d);
+  }
+  h4_t lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) lo[j] = (half_t)(v[j] - (float)hi[j]);
+  return lo;
+}
+#endif
 
 // ---- GEMM epilogues -------------------------------------------------------------------------------
 enum { ZK_EPI_STORE = 0, ZK_EPI_GELU = 1, ZK_EPI_RESID = 2, ZK_EPI_PATCH = 3 };
@@ -57,6 +85,7 @@ struct zk_gemm_args {
   float* resid;        // [M, N] fp32, in-place += (RESID) ; PATCH: hidden base
   const float* pos;    // PATCH: position embeddings [1214, 768]
   int lo_n_limit;      // STORE: write the lo plane only for n < lo_n_limit
+  int w_exp;           // ZK_F16C8: the weight's c8 plane holds (fp8(W·2^w_exp), fp8((W-Wh)·2^(w_exp+11)))
   long long* stamps;   // diagnostic only (ZK_GEMM_STAMPS): [grid][16] s_memtime stamps, nullptr in production
   int ablate;          // diagnostic only (ZK_GEMM_ABLATE): timing-only knobs, 0 in production
 };
@@ -87,3 +116,6 @@ void zk_launch_softmax2(const float* logits, int n, int num_labels, float* probs
 void zk_launch_resample(const float* in, int64_t n_in, int orig, int neu, int width, const float* kernels,
                         int klen, float* out, int64_t n_out, hipStream_t s);
 void zk_launch_split_f32(const float* src, int64_t n, float scale, half_t* hi, half_t* lo, hipStream_t s);
+// weights: c8 plane = (fp8(w·2^e), fp8((w - fp16(w))·2^(e+11))) byte pairs; activations (is_weight = 0): (fp8((x-xh)·2^11), fp8(x))
+void zk_launch_split_c8(const float* src, int64_t n, int w_exp, int is_weight, half_t* c8, hipStream_t s);
+void zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s);

@@ -38,12 +38,21 @@ struct DevBuf {
 
 struct PlaneBuf {
   DevBuf hi, lo;
-  zk_planes get(bool split) const { return zk_planes{hi.as<half_t>(), split ? lo.as<half_t>() : nullptr}; }
+  zk_planes get(bool split, int lo_fmt = ZK_LO_F16) const {
+    return zk_planes{hi.as<half_t>(), split ? lo.as<half_t>() : nullptr, lo_fmt};
+  }
+};
+
+// a weight matrix in all the forms the GEMM modes read: fp16 hi (ZK_F16), + fp16 lo (ZK_F16X3), + c8 byte pairs with
+// their power-of-two exponent (ZK_F16C8); 6 B per parameter, 0.5 GB per stage
+struct WMat {
+  half_t *hi = nullptr, *lo = nullptr, *c8 = nullptr;
+  int exp = 0;
 };
 
 struct LayerW {
   float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bo, *b1, *b2;
-  half_t *wqkv_hi, *wqkv_lo, *wo_hi, *wo_lo, *w1_hi, *w1_lo, *w2_hi, *w2_lo;
+  WMat wqkv, wo, w1, w2;
 };
 
 struct StageModel {
@@ -55,7 +64,7 @@ struct StageModel {
   float mean = 0.f, std = 1.f;
   std::vector<void*> allocs;
   float *cls = nullptr, *dist = nullptr, *pos = nullptr, *patch_b = nullptr;
-  half_t *patch_w_hi = nullptr, *patch_w_lo = nullptr;
+  WMat patch_w;
   LayerW L[ZK_LAYERS];
   float *lnf_g = nullptr, *lnf_b = nullptr, *lnh_g = nullptr, *lnh_b = nullptr, *head_w = nullptr, *head_b = nullptr;
   void release() {
@@ -229,6 +238,28 @@ float half_bits_to_float(uint16_t h) {
   float f; memcpy(&f, &out, 4); return f;
 }
 
+// OCP fp8 e4m3 (bias 7, no infinities) -> float
+float fp8_e4m3_to_float(uint8_t b) {
+  const int s = b >> 7, e = (b >> 3) & 15, m = b & 7;
+  float v;
+  if (e == 0) v = ldexpf((float)m, -9);
+  else if (e == 15 && m == 7) v = NAN;
+  else v = ldexpf((float)(8 + m), e - 10);
+  return s ? -v : v;
+}
+
+// value of a lo-plane entry: fp16 remainder, or byte 0 of the c8 pair (fp8 of the remainder times 2^11)
+float lo_entry_to_float(uint16_t bits, int lo_fmt) {
+  return lo_fmt == ZK_LO_C8 ? ldexpf(fp8_e4m3_to_float((uint8_t)(bits & 0xFF)), -ZK_C8_SHIFT) : half_bits_to_float(bits);
+}
+
+// byte 1 of a c8 pair must be the fp8 rounding of the full value (4 significant bits; subnormal step 2^-9; clamp 448)
+bool c8_value_byte_ok(uint16_t bits, float v) {
+  const float got = fp8_e4m3_to_float((uint8_t)(bits >> 8));
+  const float want = fminf(fmaxf(v, -448.f), 448.f);
+  return fabsf(got - want) <= fabsf(want) * 0.0626f + 0.001f;
+}
+
 bool to_f32(const zk_tensor_desc& t, std::vector<float>& out) {
   size_t n = 1;
   for (int i = 0; i < t.ndim; ++i) n *= (size_t)t.shape[i];
@@ -258,12 +289,26 @@ int dev_f32(zk_ctx* c, StageModel& sm, const std::vector<float>& v, float** out)
   return ZK_OK;
 }
 
-int dev_planes(zk_ctx* c, StageModel& sm, const std::vector<float>& v, half_t** hi, half_t** lo) {
+// exponent e of a weight tensor's c8 plane: the largest |w|·2^e lands in [112, 224] (fp8 e4m3 tops out at 448)
+int c8_exponent(const float* w, size_t n) {
+  float mx = 0.f;
+  for (size_t i = 0; i < n; ++i) { const float a = fabsf(w[i]); if (a > mx && a < INFINITY) mx = a; }
+  if (!(mx > 0.f)) return 0;
+  int e = (int)floorf(log2f(224.0f / mx));
+  if (e > 60) e = 60;
+  if (e < -60) e = -60;
+  return e;
+}
+
+int dev_planes(zk_ctx* c, StageModel& sm, const std::vector<float>& v, WMat* w) {
   HIPCHK(c, c->tmp_f32.ensure(v.size() * 4));
   HIPCHK(c, hipMemcpyAsync(c->tmp_f32.p, v.data(), v.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMalloc((void**)hi, v.size() * 2)); sm.allocs.push_back(*hi);
-  HIPCHK(c, hipMalloc((void**)lo, v.size() * 2)); sm.allocs.push_back(*lo);
-  zk_launch_split_f32(c->tmp_f32.as<float>(), (int64_t)v.size(), 1.0f, *hi, *lo, c->stream);
+  HIPCHK(c, hipMalloc((void**)&w->hi, v.size() * 2)); sm.allocs.push_back(w->hi);
+  HIPCHK(c, hipMalloc((void**)&w->lo, v.size() * 2)); sm.allocs.push_back(w->lo);
+  HIPCHK(c, hipMalloc((void**)&w->c8, v.size() * 2)); sm.allocs.push_back(w->c8);
+  w->exp = c8_exponent(v.data(), v.size());
+  zk_launch_split_c8(c->tmp_f32.as<float>(), (int64_t)v.size(), w->exp, 1, w->c8, c->stream);
+  zk_launch_split_f32(c->tmp_f32.as<float>(), (int64_t)v.size(), 1.0f, w->hi, w->lo, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ZK_OK;
@@ -295,31 +340,35 @@ int ensure_workspace(zk_ctx* c, int windows, bool split) {
   return ZK_OK;
 }
 
-void run_gemm(zk_ctx* c, int cls, zk_planes x, const half_t* w_hi, const half_t* w_lo, const float* bias, int M, int N,
-              int K, int epi, int nsplit, zk_planes out, float* resid, const float* pos, int lo_n_limit) {
+void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, int M, int N, int K, int epi, int nsplit,
+              zk_planes out, float* resid, const float* pos, int lo_n_limit) {
   ProfScope ps(c, cls);
   if (c->prof) c->prof_flops[cls] += 2.0 * M * (double)N * K;
   zk_gemm_args a;
-  a.x_hi = x.hi; a.x_lo = x.lo; a.w_hi = w_hi; a.w_lo = w_lo; a.bias = bias;
+  a.x_hi = x.hi; a.x_lo = x.lo; a.w_hi = w.hi; a.w_lo = (nsplit == ZK_F16C8) ? w.c8 : w.lo; a.bias = bias;
   a.M = M; a.N = N; a.K = K;
-  a.o_hi = out.hi; a.o_lo = (nsplit == 3) ? out.lo : nullptr;
-  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.stamps = nullptr; a.ablate = 0;
-  zk_launch_gemm(a, epi, nsplit, c->stream);
+  a.o_hi = out.hi; a.o_lo = (nsplit != ZK_F16) ? out.lo : nullptr;
+  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.w_exp = w.exp; a.stamps = nullptr; a.ablate = 0;
+  if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
+  else zk_launch_gemm(a, epi, nsplit, c->stream);
 }
 
 // forward of nb windows (one micro-batch) whose patch matrix is already in c->patchA
 int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
   const int ns = sm.mode;
-  const bool sp = ns == 3;
+  const bool sp = ns != ZK_F16;
+  // lo-plane format of every GEMM operand: c8 byte pairs in ZK_F16C8; the QKV planes keep an fp16 lo (split QK^T)
+  const int lf = (ns == ZK_F16C8) ? ZK_LO_C8 : ZK_LO_F16;
   const int M = nb * ZK_SEQ;
   float* hidden = c->hidden.as<float>();
-  zk_planes pa = c->patchA.get(sp), xn = c->xn.get(sp), qkv = c->qkv.get(sp), att = c->att.get(sp), mid = c->mid.get(sp);
+  zk_planes pa = c->patchA.get(sp, lf), xn = c->xn.get(sp, lf), qkv = c->qkv.get(sp), att = c->att.get(sp, lf),
+            mid = c->mid.get(sp, lf);
   {
     ProfScope ps(c, P_EMBED);
     zk_launch_cls_rows(hidden, sm.cls, sm.dist, sm.pos, nb, c->stream);
   }
-  run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w_hi, sm.patch_w_lo, sm.patch_b, nb * ZK_NPATCH, ZK_HIDDEN, ZK_PATCH_K,
-           ZK_EPI_PATCH, ns, zk_planes{nullptr, nullptr}, hidden, sm.pos, 0);
+  run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w, sm.patch_b, nb * ZK_NPATCH, ZK_HIDDEN, ZK_PATCH_K,
+           ZK_EPI_PATCH, ns, zk_planes{nullptr, nullptr, 0}, hidden, sm.pos, 0);
   if (c->tap_layer == -1) {
     HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
     HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -333,35 +382,35 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
     // token.  Disabled while a debug tap wants the full residual stream of that layer.
     const bool last = (l == sm.n_layers - 1) && c->prune_last && c->tap_layer != l;
     { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, M, xn, sm.eps, c->stream); }
-    run_gemm(c, P_GEMM_QKV, xn, L.wqkv_hi, L.wqkv_lo, L.bqkv, M, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv,
+    run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, M, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv,
              nullptr, nullptr, 2 * ZK_HIDDEN);
     {
       ProfScope ps(c, P_ATTN);
       const int qt = last ? 1 : 10;
       if (c->prof) c->prof_flops[P_ATTN] += (double)nb * ZK_HEADS * 4.0 * (qt == 1 ? 128.0 : (double)ZK_SEQ) * ZK_SEQ * ZK_HEAD_DIM;
-      zk_launch_attention(qkv, att, nb, ns, qt, c->stream);
+      zk_launch_attention(qkv, att, nb, sp ? 3 : 1, qt, c->stream);
     }
     if (last) {
-      zk_planes att_s = c->att_s.get(sp), xn_s = c->xn_s.get(sp), mid_s = c->mid_s.get(sp);
+      zk_planes att_s = c->att_s.get(sp, lf), xn_s = c->xn_s.get(sp, lf), mid_s = c->mid_s.get(sp, lf);
       float* hs = c->hidden_s.as<float>();
       { ProfScope ps(c, P_EMBED); zk_launch_gather_tok01(att, hidden, nb, att_s, hs, c->stream); }
-      run_gemm(c, P_GEMM_O, att_s, L.wo_hi, L.wo_lo, L.bo, 2 * nb, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
-               zk_planes{nullptr, nullptr}, hs, nullptr, 0);
+      run_gemm(c, P_GEMM_O, att_s, L.wo, L.bo, 2 * nb, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
+               zk_planes{nullptr, nullptr, 0}, hs, nullptr, 0);
       { ProfScope ps(c, P_LN); zk_launch_layernorm(hs, ZK_HIDDEN, L.ln2_g, L.ln2_b, 2 * nb, xn_s, sm.eps, c->stream); }
-      run_gemm(c, P_GEMM_FC1, xn_s, L.w1_hi, L.w1_lo, L.b1, 2 * nb, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid_s, nullptr,
+      run_gemm(c, P_GEMM_FC1, xn_s, L.w1, L.b1, 2 * nb, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid_s, nullptr,
                nullptr, ZK_INTER);
-      run_gemm(c, P_GEMM_FC2, mid_s, L.w2_hi, L.w2_lo, L.b2, 2 * nb, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
-               zk_planes{nullptr, nullptr}, hs, nullptr, 0);
+      run_gemm(c, P_GEMM_FC2, mid_s, L.w2, L.b2, 2 * nb, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
+               zk_planes{nullptr, nullptr, 0}, hs, nullptr, 0);
       pruned = true;
       continue;
     }
-    run_gemm(c, P_GEMM_O, att, L.wo_hi, L.wo_lo, L.bo, M, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
-             zk_planes{nullptr, nullptr}, hidden, nullptr, 0);
+    run_gemm(c, P_GEMM_O, att, L.wo, L.bo, M, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
+             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0);
     { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln2_g, L.ln2_b, M, xn, sm.eps, c->stream); }
-    run_gemm(c, P_GEMM_FC1, xn, L.w1_hi, L.w1_lo, L.b1, M, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid, nullptr, nullptr,
+    run_gemm(c, P_GEMM_FC1, xn, L.w1, L.b1, M, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid, nullptr, nullptr,
              ZK_INTER);
-    run_gemm(c, P_GEMM_FC2, mid, L.w2_hi, L.w2_lo, L.b2, M, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
-             zk_planes{nullptr, nullptr}, hidden, nullptr, 0);
+    run_gemm(c, P_GEMM_FC2, mid, L.w2, L.b2, M, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
+             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0);
     if (c->tap_layer == l) {
       HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
       HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -380,7 +429,8 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
 // src_full != nullptr: device (B,1024,128) normalised; else feature slot with optional device index list
 int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d_idx, int B, float* d_logits) {
   StageModel& sm = c->model[stage];
-  const bool sp = sm.mode == 3;
+  const bool sp = sm.mode != ZK_F16;
+  const int lf = (sm.mode == ZK_F16C8) ? ZK_LO_C8 : ZK_LO_F16;
   // micro_batch == 0: pick the size whose 256-row tile count fills the 256 persistent workgroups with the least
   // round-up waste for the N=768 GEMMs (3 column tiles): tiles_m*3 just below a multiple of 256.
   int mbs = c->micro_batch;
@@ -399,11 +449,11 @@ int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d
     {
       ProfScope ps(c, P_EMBED);
       if (src_full)
-        zk_launch_im2col_full(src_full + (size_t)b0 * ZK_MAXLEN * ZK_NMEL, nb, c->patchA.get(sp), c->stream);
+        zk_launch_im2col_full(src_full + (size_t)b0 * ZK_MAXLEN * ZK_NMEL, nb, c->patchA.get(sp, lf), c->stream);
       else
         zk_launch_im2col_compact(c->feat.as<float>() + (d_idx ? 0 : (size_t)b0 * c->feat_frames * ZK_NMEL),
                                  c->feat_frames, d_idx ? d_idx + b0 : nullptr, nb, sm.mean, sm.std * 2.0f,
-                                 c->patchA.get(sp), c->stream);
+                                 c->patchA.get(sp, lf), c->stream);
     }
     if (tapped) c->tap_layer = -2;  // tap only the first micro-batch
     rc = forward_micro(c, sm, nb, d_logits + (size_t)b0 * sm.num_labels);
@@ -523,7 +573,8 @@ int zk_model_load(zk_ctx* c, int stage, const zk_tensor_desc* t, int32_t n, cons
   if (!c) return ZK_E_ARG;
   if (stage < 0 || stage > 1) return fail(c, ZK_E_ARG, "stage must be 0 or 1");
   if (!t || n <= 0 || !cfg) return fail(c, ZK_E_ARG, "tensors/cfg missing");
-  if (mode != ZK_F16 && mode != ZK_F16X3) return fail(c, ZK_E_ARG, "compute_mode must be ZK_F16 (1) or ZK_F16X3 (3)");
+  if (mode != ZK_F16 && mode != ZK_F16X3 && mode != ZK_F16C8)
+    return fail(c, ZK_E_ARG, "compute_mode must be ZK_F16 (1), ZK_F16C8 (2) or ZK_F16X3 (3)");
   if (cfg->hidden_size != ZK_HIDDEN || cfg->num_attention_heads != ZK_HEADS || cfg->intermediate_size != ZK_INTER ||
       cfg->patch_size != ZK_PATCH || cfg->frequency_stride != ZK_FSTRIDE || cfg->time_stride != ZK_TSTRIDE ||
       cfg->max_length != ZK_MAXLEN || cfg->num_mel_bins != ZK_NMEL)
@@ -551,12 +602,12 @@ int zk_model_load(zk_ctx* c, int stage, const zk_tensor_desc* t, int32_t n, cons
   };
   int rc;
 #define NEEDF(dst, want, ...) do { if ((rc = need({__VA_ARGS__}, (want), v))) return rc; if ((rc = dev_f32(c, sm, v, &(dst)))) return rc; } while (0)
-#define NEEDP(hi, lo, want, ...) do { if ((rc = need({__VA_ARGS__}, (want), v))) return rc; if ((rc = dev_planes(c, sm, v, &(hi), &(lo)))) return rc; } while (0)
+#define NEEDP(w, want, ...) do { if ((rc = need({__VA_ARGS__}, (want), v))) return rc; if ((rc = dev_planes(c, sm, v, &(w)))) return rc; } while (0)
   NEEDF(sm.cls, ZK_HIDDEN, P + "embeddings.cls_token");
   NEEDF(sm.dist, ZK_HIDDEN, P + "embeddings.distillation_token");
   NEEDF(sm.pos, (size_t)ZK_SEQ * ZK_HIDDEN, P + "embeddings.position_embeddings");
   NEEDF(sm.patch_b, ZK_HIDDEN, P + "embeddings.patch_embeddings.projection.bias");
-  NEEDP(sm.patch_w_hi, sm.patch_w_lo, (size_t)ZK_HIDDEN * ZK_PATCH_K, P + "embeddings.patch_embeddings.projection.weight");
+  NEEDP(sm.patch_w, (size_t)ZK_HIDDEN * ZK_PATCH_K, P + "embeddings.patch_embeddings.projection.weight");
   for (int l = 0; l < sm.n_layers; ++l) {
     LayerW& L = sm.L[l];
     const std::string a5 = P + "layers." + std::to_string(l) + ".";
@@ -571,13 +622,13 @@ int zk_model_load(zk_ctx* c, int stage, const zk_tensor_desc* t, int32_t n, cons
       if ((rc = need({a5 + n5[j] + ".bias", a4 + n4[j] + ".bias"}, ZK_HIDDEN, v))) return rc;
       memcpy(bq.data() + (size_t)j * ZK_HIDDEN, v.data(), v.size() * 4);
     }
-    if ((rc = dev_planes(c, sm, wq, &L.wqkv_hi, &L.wqkv_lo))) return rc;
+    if ((rc = dev_planes(c, sm, wq, &L.wqkv))) return rc;
     if ((rc = dev_f32(c, sm, bq, &L.bqkv))) return rc;
-    NEEDP(L.wo_hi, L.wo_lo, (size_t)ZK_HIDDEN * ZK_HIDDEN, a5 + "attention.o_proj.weight", a4 + "attention.output.dense.weight");
+    NEEDP(L.wo, (size_t)ZK_HIDDEN * ZK_HIDDEN, a5 + "attention.o_proj.weight", a4 + "attention.output.dense.weight");
     NEEDF(L.bo, ZK_HIDDEN, a5 + "attention.o_proj.bias", a4 + "attention.output.dense.bias");
-    NEEDP(L.w1_hi, L.w1_lo, (size_t)ZK_INTER * ZK_HIDDEN, a5 + "mlp.fc1.weight", a4 + "intermediate.dense.weight");
+    NEEDP(L.w1, (size_t)ZK_INTER * ZK_HIDDEN, a5 + "mlp.fc1.weight", a4 + "intermediate.dense.weight");
     NEEDF(L.b1, ZK_INTER, a5 + "mlp.fc1.bias", a4 + "intermediate.dense.bias");
-    NEEDP(L.w2_hi, L.w2_lo, (size_t)ZK_INTER * ZK_HIDDEN, a5 + "mlp.fc2.weight", a4 + "output.dense.weight");
+    NEEDP(L.w2, (size_t)ZK_INTER * ZK_HIDDEN, a5 + "mlp.fc2.weight", a4 + "output.dense.weight");
     NEEDF(L.b2, ZK_HIDDEN, a5 + "mlp.fc2.bias", a4 + "output.dense.bias");
     NEEDF(L.ln1_g, ZK_HIDDEN, a5 + "layernorm_before.weight", a4 + "layernorm_before.weight");
     NEEDF(L.ln1_b, ZK_HIDDEN, a5 + "layernorm_before.bias", a4 + "layernorm_before.bias");
@@ -599,7 +650,7 @@ int zk_model_load(zk_ctx* c, int stage, const zk_tensor_desc* t, int32_t n, cons
 int zk_model_set_compute_mode(zk_ctx* c, int stage, int32_t mode) {
   int rc = check_stage(c, stage);
   if (rc) return rc;
-  if (mode != ZK_F16 && mode != ZK_F16X3) return fail(c, ZK_E_ARG, "compute_mode must be 1 or 3");
+  if (mode != ZK_F16 && mode != ZK_F16X3 && mode != ZK_F16C8) return fail(c, ZK_E_ARG, "compute_mode must be 1, 2 or 3");
   c->model[stage].mode = mode;
   return ZK_OK;
 }
@@ -865,13 +916,19 @@ int zk_test_layernorm(zk_ctx* c, const float* x, const float* gamma, const float
   HIPCHK(c, hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dg, gamma, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(db, beta, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
-  zk_launch_layernorm(dx, ZK_HIDDEN, dg, db, rows, zk_planes{hi, nsplit == 3 ? lo : nullptr}, eps, c->stream);
+  const int lf = nsplit == ZK_F16C8 ? ZK_LO_C8 : ZK_LO_F16;
+  zk_launch_layernorm(dx, ZK_HIDDEN, dg, db, rows, zk_planes{hi, nsplit != ZK_F16 ? lo : nullptr, lf}, eps, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<uint16_t> h(n), l(n, 0);
   HIPCHK(c, hipMemcpy(h.data(), hi, n * 2, hipMemcpyDeviceToHost));
-  if (nsplit == 3) HIPCHK(c, hipMemcpy(l.data(), lo, n * 2, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < n; ++i) out[i] = half_bits_to_float(h[i]) + (nsplit == 3 ? half_bits_to_float(l[i]) : 0.f);
+  if (nsplit != ZK_F16) HIPCHK(c, hipMemcpy(l.data(), lo, n * 2, hipMemcpyDeviceToHost));
+  size_t bad = 0;
+  for (size_t i = 0; i < n; ++i) {
+    out[i] = half_bits_to_float(h[i]) + (nsplit != ZK_F16 ? lo_entry_to_float(l[i], lf) : 0.f);
+    if (lf == ZK_LO_C8 && !c8_value_byte_ok(l[i], out[i])) ++bad;
+  }
   (void)hipFree(dx); (void)hipFree(dg); (void)hipFree(db); (void)hipFree(hi); (void)hipFree(lo);
+  if (bad) return fail(c, ZK_E_STATE, "layernorm c8 plane: %zu value bytes are not the fp8 rounding of the output", bad);
   return ZK_OK;
 }
 
@@ -894,6 +951,12 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   HIPCHK(c, hipMemcpy(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice));
   zk_launch_split_f32(dx, (int64_t)nx, 1.f, xh, xl, c->stream);
   zk_launch_split_f32(dw, (int64_t)nw, 1.f, wh, wl, c->stream);
+  int w_exp = 0;
+  if (nsplit == ZK_F16C8) {      // lo planes become c8 byte pairs
+    w_exp = c8_exponent(w, nw);
+    zk_launch_split_c8(dx, (int64_t)nx, 0, 0, xl, c->stream);
+    zk_launch_split_c8(dw, (int64_t)nw, w_exp, 1, wl, c->stream);
+  }
   if (epi == ZK_EPI_RESID || epi == ZK_EPI_PATCH) {
     HIPCHK(c, hipMalloc((void**)&dres, no * 4));
     HIPCHK(c, hipMemcpy(dres, out, no * 4, hipMemcpyHostToDevice));
@@ -903,8 +966,9 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
     HIPCHK(c, hipMemset(ol, 0, no * 2));
   }
   zk_gemm_args a;
-  a.x_hi = xh; a.x_lo = nsplit == 3 ? xl : nullptr; a.w_hi = wh; a.w_lo = nsplit == 3 ? wl : nullptr; a.bias = dbias;
-  a.M = M; a.N = N; a.K = K; a.o_hi = oh; a.o_lo = nsplit == 3 ? ol : nullptr; a.resid = dres; a.pos = dpos; a.lo_n_limit = N;
+  a.x_hi = xh; a.x_lo = nsplit != ZK_F16 ? xl : nullptr; a.w_hi = wh; a.w_lo = nsplit != ZK_F16 ? wl : nullptr; a.bias = dbias;
+  a.M = M; a.N = N; a.K = K; a.o_hi = oh; a.o_lo = nsplit != ZK_F16 ? ol : nullptr; a.resid = dres; a.pos = dpos; a.lo_n_limit = N;
+  a.w_exp = w_exp;
   a.stamps = nullptr;
   a.ablate = getenv("ZK_GEMM_ABLATE") ? atoi(getenv("ZK_GEMM_ABLATE")) : 0;
   long long* dstamps = nullptr;
@@ -913,9 +977,25 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
     HIPCHK(c, hipMemset(dstamps, 0, 256 * 16 * 8));
     a.stamps = dstamps;
   }
-  zk_launch_gemm(a, epi, nsplit, c->stream);
+  if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
+  else zk_launch_gemm(a, epi, nsplit, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (dstamps && nsplit == ZK_F16C8) {
+    std::vector<long long> st(256 * 16);
+    HIPCHK(c, hipMemcpy(st.data(), dstamps, st.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, clk = 0; int nb = 0;
+    for (int b = 0; b < 256; ++b) {
+      const long long* s = &st[(size_t)b * 16];
+      if (!s[0] || !s[13] || s[15] <= s[14]) continue;
+      cyc += (double)(s[13] - s[1]); clk += (double)(s[13] - s[0]) / (double)(s[15] - s[14]) * 100.0; ++nb;
+    }
+    const int tiles = ((M + 255) / 256) * (N / 256);
+    const double steps = (double)((tiles + 255) / 256) * (K / 64) * 2;
+    if (nb) fprintf(stderr, "[stamps c8] M=%d N=%d K=%d epi=%d blocks=%d: %.0f ticks per ring step (incl. epilogues), shader clock %.0f MHz\n",
+                    M, N, K, epi, nb, cyc / nb / steps, clk / nb);
+    (void)hipFree(dstamps); dstamps = nullptr;
+  }
   if (dstamps) {
     std::vector<long long> st(256 * 16);
     HIPCHK(c, hipMemcpy(st.data(), dstamps, st.size() * 8, hipMemcpyDeviceToHost));
@@ -946,7 +1026,13 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
     std::vector<uint16_t> h(no), l(no);
     HIPCHK(c, hipMemcpy(h.data(), oh, no * 2, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(l.data(), ol, no * 2, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < no; ++i) out[i] = half_bits_to_float(h[i]) + half_bits_to_float(l[i]);
+    const int lf = (nsplit == ZK_F16C8 && epi == ZK_EPI_GELU) ? ZK_LO_C8 : ZK_LO_F16;
+    size_t bad = 0;
+    for (size_t i = 0; i < no; ++i) {
+      out[i] = half_bits_to_float(h[i]) + lo_entry_to_float(l[i], lf);
+      if (lf == ZK_LO_C8 && !c8_value_byte_ok(l[i], out[i])) ++bad;
+    }
+    if (bad) return fail(c, ZK_E_STATE, "gemm GELU c8 plane: %zu value bytes are not the fp8 rounding of the output", bad);
   }
   for (void* p : {(void*)dx, (void*)dw, (void*)dbias, (void*)dres, (void*)dpos, (void*)xh, (void*)xl, (void*)wh, (void*)wl, (void*)oh, (void*)ol})
     if (p) (void)hipFree(p);
@@ -964,13 +1050,20 @@ int zk_test_attention(zk_ctx* c, const float* qkv, int32_t W, int32_t nsplit, fl
   HIPCHK(c, hipMemset(ol, 0, no * 2));
   HIPCHK(c, hipMemcpy(dq, qkv, nq * 4, hipMemcpyHostToDevice));
   zk_launch_split_f32(dq, (int64_t)nq, 1.f, qh, ql, c->stream);
-  zk_launch_attention(zk_planes{qh, nsplit == 3 ? ql : nullptr}, zk_planes{oh, nsplit == 3 ? ol : nullptr}, W, nsplit, 0, c->stream);
+  const int lf = nsplit == ZK_F16C8 ? ZK_LO_C8 : ZK_LO_F16;
+  zk_launch_attention(zk_planes{qh, nsplit != ZK_F16 ? ql : nullptr, ZK_LO_F16}, zk_planes{oh, nsplit != ZK_F16 ? ol : nullptr, lf}, W,
+                      nsplit != ZK_F16 ? 3 : 1, 0, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<uint16_t> h(no), l(no);
   HIPCHK(c, hipMemcpy(h.data(), oh, no * 2, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(l.data(), ol, no * 2, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < no; ++i) out[i] = half_bits_to_float(h[i]) + half_bits_to_float(l[i]);
+  size_t bad = 0;
+  for (size_t i = 0; i < no; ++i) {
+    out[i] = half_bits_to_float(h[i]) + lo_entry_to_float(l[i], lf);
+    if (lf == ZK_LO_C8 && !c8_value_byte_ok(l[i], out[i])) ++bad;
+  }
+  if (bad) return fail(c, ZK_E_STATE, "attention c8 plane: %zu value bytes are not the fp8 rounding of the output", bad);
   (void)hipFree(dq); (void)hipFree(qh); (void)hipFree(ql); (void)hipFree(oh); (void)hipFree(ol);
   return ZK_OK;
 }

@@ -17,10 +17,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkast.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
-ZK_F16, ZK_F16X3 = 1, 3
+ZK_F16, ZK_F16C8, ZK_F16X3 = 1, 2, 3
 ZK_DT_F32, ZK_DT_F16, ZK_DT_BF16 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_PATCH = 0, 1, 2, 3
-COMPUTE_MODES = {"f16": ZK_F16, "f16x3": ZK_F16X3, 1: ZK_F16, 3: ZK_F16X3}
+COMPUTE_MODES = {"f16": ZK_F16, "f16c8": ZK_F16C8, "f16x3": ZK_F16X3, 1: ZK_F16, 2: ZK_F16C8, 3: ZK_F16X3}
 
 # every symbol include/zkast.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
