@@ -14,9 +14,9 @@ for (N, K, epi) in [(2304, 768, lib.EPI_STORE), (768, 768, lib.EPI_RESID), (3072
     b = np.zeros(N, np.float32)
     r0 = np.zeros((M, N), np.float32) if epi == lib.EPI_RESID else None
     outs = {}
-    for ns in (3, 2):
+    for ns in ((2,) if os.environ.get('ONLY_C8') else (3, 2)):
         for _ in range(2):
             outs[ns] = ctx.test_gemm(x, w, b, epi, ns, resid=None if r0 is None else r0.copy())
-    d = np.abs(outs[2] - outs[3]).max() / np.abs(outs[3]).max()
+    d = np.abs(outs[2] - outs[3]).max() / np.abs(outs[3]).max() if 3 in outs else -1.0
     print(f"N={N} K={K} epi={epi}: c8 vs x3 max rel-to-scale diff {d:.2e}", flush=True)
 print("done")

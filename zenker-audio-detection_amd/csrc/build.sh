@@ -3,6 +3,7 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../zkast"
+LIBNAME="${ZK_LIB_NAME:-libzkast.so}"          # ZK_LIB_NAME / ZK_OBJ_DIR / ZK_EXTRA_FLAGS: experiment builds (tools/)
 OBJ="${ZK_OBJ_DIR:-$HERE/build}"
 mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
@@ -17,10 +18,10 @@ for f in gemm gemm_c8 attention layernorm embed head logmel misc zkast; do
     # attention: scores are finite by construction (masking uses -1e30, not -inf), so fmax needs no sNaN-quieting
     # v_max x,x in front of every MFMA output (48 extra VALU per key tile otherwise)
     [ "$f" = "attention" ] && EXTRA="-fno-honor-nans"
-    $HIPCC $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
+    $HIPCC $FLAGS ${ZK_EXTRA_FLAGS:-} $EXTRA -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libzkast.so" "$OBJ"/{gemm,gemm_c8,attention,layernorm,embed,head,logmel,misc,zkast}.o
-echo "built $OUT/libzkast.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIBNAME" "$OBJ"/{gemm,gemm_c8,attention,layernorm,embed,head,logmel,misc,zkast}.o
+echo "built $OUT/$LIBNAME"

@@ -27,7 +27,49 @@
 
 #include "gemm_util.h"
 
+// ZK_C8_ABLATE (compile-time, tools/ experiments only; results are WRONG with any bit set): 1 = no LDS-DMA pieces in the
+// loop, 2 = no wait for the prefetched step, 4 = no per-step barrier, 8 = no X fragment reads after tile 0
+#ifndef ZK_C8_ABLATE
+#define ZK_C8_ABLATE 0
+#endif
+// ZK_C8_SCHED: where the 8 LDS-DMA pieces of the next step are issued (pieces per chunk; chunk -1 is the deferred tile
+// right behind the barrier, chunks 0..6 follow)
+// ZK_C8_TIMING (experiments): waves 0 and 4 (same SIMD) sum the s_memtime ticks of [barrier release -> end of chunks],
+// [-> prefetch landed], [-> barrier release] into stamps[6..8] / [9..11]
+#ifndef ZK_C8_TIMING
+#define ZK_C8_TIMING 0
+#endif
+#ifndef ZK_C8_SCHED
+#define ZK_C8_SCHED 3
+#endif
+
 namespace {
+
+// pieces issued in chunk c (-1..6) and the index of its first piece
+constexpr int c8_cnt(int c) {
+  constexpr int T[4][8] = {{0, 4, 4, 0, 0, 0, 0, 0},      // 0: chunks 0,1
+                           {0, 2, 2, 2, 2, 0, 0, 0},      // 1: chunks 0..3
+                           {1, 1, 1, 1, 1, 1, 1, 1},      // 2: one per chunk incl. the deferred one
+                           {2, 2, 2, 2, 0, 0, 0, 0}};     // 3: deferred + chunks 0..2
+  return T[ZK_C8_SCHED][c + 1];
+}
+constexpr int c8_base(int c) { int b = 0; for (int q = -1; q < c; ++q) b += c8_cnt(q); return b; }
+// piece to issue in front of MFMA group g (of G) of chunk c, or -1
+constexpr int c8_piece(int c, int g, int G) {
+  const int n = c8_cnt(c);
+  for (int q = 0; q < n; ++q) if (q * G / n == g) return c8_base(c) + q;
+  return -1;
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I in [0, N) — the loop index ends up in "n" asm operands
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 typedef int i4v_t __attribute__((ext_vector_type(4)));
 typedef int i8v_t __attribute__((ext_vector_type(8)));
@@ -144,11 +186,19 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   const int fsw = (lane >> 1) & 7;
   const int xoff = (wm * TM + frow) * ROWB + ((fq ^ fsw) & 7) * 16;
   const int woff = XBYTES + (wn * TN + frow) * ROWB + ((fq ^ fsw) & 7) * 16;
-  auto ld_frag = [&](const char* slot, int off, int tile) __attribute__((always_inline)) -> frag_t {
-    frag_t f;
-    f.a = *(const i4v_t*)(slot + off + tile * TILE_B);
-    f.b = *(const i4v_t*)(slot + (off ^ 64) + tile * TILE_B);
-    return f;
+  // Fragment reads are inline asm with HAND-COUNTED s_waitcnt lgkmcnt: hipcc's own placement waits lgkmcnt(0) in front
+  // of a chunk's first MFMA, i.e. also for the two reads of the NEXT tile issued just before — an exposed LDS round
+  // trip per chunk.  LDS reads retire in order, so "all but the newest two" is lgkmcnt(2).  The wait statements name
+  // the fragments they make valid as in/out operands so that no MFMA can be scheduled in front of them.
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;      // LDS byte address of the ring (low half of the flat address)
+  const unsigned xad[2] = {lds0 + (unsigned)xoff, lds0 + (unsigned)(xoff ^ 64)};
+  const unsigned wad[2] = {lds0 + (unsigned)woff, lds0 + (unsigned)(woff ^ 64)};
+  auto ld_frag = [&](frag_t& f, auto slot_c, const unsigned (&ad)[2], auto tile_c) __attribute__((always_inline)) {
+    constexpr int IMM = decltype(tile_c)::value * TILE_B;
+    constexpr unsigned SLOT = decltype(slot_c)::value * STAGE;
+    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
+                 : "=&v"(f.a), "=&v"(f.b)
+                 : "v"(ad[0] + SLOT), "v"(ad[1] + SLOT), "n"(IMM));
   };
   // e8m0 block scales of the fp8 MFMA: W' side 2^-(w_exp + 11), X' side 1
   const int sc_w = (127 - (a.w_exp + ZK_C8_SHIFT)) * 0x01010101;
@@ -282,21 +332,24 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 
   int c_k = 0;
   bool epi_pending = false;
+#if ZK_C8_TIMING
+  long long tm_a = 0, tm_b = 0, tm_c = 0, tm_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
 
   // one ring step of kind KIND (its slot), prefetching the following step (kind KIND^1) into the other slot
   auto step = [&](auto kind_c) __attribute__((always_inline)) {
     constexpr int KIND = decltype(kind_c)::value;
     using KN = std::integral_constant<int, KIND ^ 1>;
-    const char* slot = smem + KIND * STAGE;
     // X tile 0 of this step, then per W tile i: the deferred MFMA of the previous step (old wf[i], X tile RM-1 in
     // xf[1]) followed by the read of this step's W fragment INTO wf[i] — one W register set serves both steps
-    xf[0] = ld_frag(slot, xoff, 0);
-#pragma unroll
-    for (int i = 0; i < RN; ++i) {
+    ld_frag(xf[0], kind_c, xad, std::integral_constant<int, 0>{});
+    static_for<RN>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      if (!(ZK_C8_ABLATE & 1) && c8_piece(-1, i, RN) >= 0) issue_piece(KN{}, c8_piece(-1, i, RN));
       mma(KN{}, H0{}, acc[i][RM - 1], wf[i], xf[1]);      // (very first step: zero fragments)
       mma(KN{}, H1{}, acc[i][RM - 1], wf[i], xf[1]);
-      wf[i] = ld_frag(slot, woff, i);
-    }
+      ld_frag(wf[i], kind_c, wad, ic);
+    });
     if constexpr (KIND == 0) {
       if (epi_pending) {
         epilogue();
@@ -304,34 +357,50 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    // chunks j = 0 .. RM-2: read X tile j+1 first (pinned in front of the MFMAs, consumed one chunk later), then the
-    // MFMAs of tile j with the 8 LDS-DMA pieces of the next step spread over chunks 0 and 1 (one per 32 MFMA cycles)
-#pragma unroll
-    for (int j = 0; j < RM - 1; ++j) {
-      xf[(j + 1) & 1] = ld_frag(slot, xoff, j + 1);
+    // chunks j = 0 .. RM-2: issue the reads of X tile j+1, wait for everything older (tile j; in chunk 0 also the W
+    // fragments), then the MFMAs of tile j with the LDS-DMA pieces of the next step in between (c8_piece)
+    static_for<RM - 1>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      ld_frag(xf[(j + 1) & 1], kind_c, xad, std::integral_constant<int, j + 1>{});
+      if constexpr (j == 0)
+        asm volatile("s_waitcnt lgkmcnt(2)"
+                     : "+v"(xf[0].a), "+v"(xf[0].b), "+v"(wf[0].a), "+v"(wf[0].b), "+v"(wf[1].a), "+v"(wf[1].b),
+                       "+v"(wf[2].a), "+v"(wf[2].b), "+v"(wf[3].a), "+v"(wf[3].b));
+      else
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xf[j & 1].a), "+v"(xf[j & 1].b));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < RN; ++i) {
-        if (j < 2 && (KIND == 1 || (i & 1) == 0)) issue_piece(KN{}, j * 4 + (KIND == 1 ? i : i / 2));
+        constexpr int G = KIND == 1 ? RN : 2 * RN;
+        if (!(ZK_C8_ABLATE & 1) && c8_piece(j, i, G) >= 0) issue_piece(KN{}, c8_piece(j, i, G));
         mma(kind_c, H0{}, acc[i][j], wf[i], xf[j & 1]);
       }
       if constexpr (KIND == 0) {
 #pragma unroll
         for (int i = 0; i < RN; ++i) {
-          if (j < 2 && (i & 1) == 0) issue_piece(KN{}, j * 4 + 2 + i / 2);
+          if (!(ZK_C8_ABLATE & 1) && c8_piece(j, RN + i, 2 * RN) >= 0) issue_piece(KN{}, c8_piece(j, RN + i, 2 * RN));
           mma(kind_c, H1{}, acc[i][j], wf[i], xf[j & 1]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     advance_load(KN{});
     if (KIND == 1) {
       if (++c_k == nk) { c_k = 0; epi_pending = true; }
     }
     // the next step must have landed; X tile RM-1 of this step (xf[1]) and wf[] are in registers
-    wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+#if ZK_C8_TIMING
+    { const long long t = (long long)__builtin_amdgcn_s_memtime(); tm_a += t - tm_last; tm_last = t; }
+#endif
+    if (!(ZK_C8_ABLATE & 2)) wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[1].a), "+v"(xf[1].b) : : "memory");      // X tile RM-1 is in xf[1]
+#if ZK_C8_TIMING
+    { const long long t = (long long)__builtin_amdgcn_s_memtime(); tm_b += t - tm_last; tm_last = t; }
+#endif
+    if (!(ZK_C8_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+#if ZK_C8_TIMING
+    { const long long t = (long long)__builtin_amdgcn_s_memtime(); tm_c += t - tm_last; tm_last = t; }
+#endif
   };
 
 #pragma unroll
@@ -341,11 +410,18 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
     step(K0{});
     step(K1{});
   }
+  if (ZK_C8_ABLATE & 2) wait_vmcnt<0>();
   // deferred tile of the last step (kind 1)
 #pragma unroll
   for (int i = 0; i < RN; ++i) mma(K1{}, H0{}, acc[i][RM - 1], wf[i], xf[1]);
   epilogue();
   if (stamp) { st[13] = (long long)__builtin_amdgcn_s_memtime(); st[15] = (long long)__builtin_amdgcn_s_memrealtime(); }
+#if ZK_C8_TIMING
+  if (a.stamps != nullptr && lane == 0 && (wave == 0 || wave == 4)) {
+    long long* o = st + (wave == 0 ? 6 : 9);
+    o[0] = tm_a; o[1] = tm_b; o[2] = tm_c;
+  }
+#endif
 }
 
 template <int EPI>

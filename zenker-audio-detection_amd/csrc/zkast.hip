@@ -994,6 +994,12 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
     const double steps = (double)((tiles + 255) / 256) * (K / 64) * 2;
     if (nb) fprintf(stderr, "[stamps c8] M=%d N=%d K=%d epi=%d blocks=%d: %.0f ticks per ring step (incl. epilogues), shader clock %.0f MHz\n",
                     M, N, K, epi, nb, cyc / nb / steps, clk / nb);
+    {   // ZK_C8_TIMING builds only (zeros otherwise)
+      double f[6] = {0}; int nf = 0;
+      for (int b = 0; b < 256; ++b) { const long long* s = &st[(size_t)b * 16]; if (!s[6]) continue; for (int q = 0; q < 6; ++q) f[q] += (double)s[6 + q]; ++nf; }
+      if (nf) fprintf(stderr, "[timing c8] per ring step: wave0 work %.0f land %.0f barrier %.0f | wave4 work %.0f land %.0f barrier %.0f\n",
+                      f[0]/nf/steps, f[1]/nf/steps, f[2]/nf/steps, f[3]/nf/steps, f[4]/nf/steps, f[5]/nf/steps);
+    }
     (void)hipFree(dstamps); dstamps = nullptr;
   }
   if (dstamps) {

@@ -14,7 +14,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkast.so")
+# ZKAST_LIB: alternative build of the same library (kernel experiments under tools/); default is the in-tree build
+LIB_PATH = os.environ.get("ZKAST_LIB") or os.path.join(_HERE, "libzkast.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 ZK_F16, ZK_F16C8, ZK_F16X3 = 1, 2, 3
