@@ -11,8 +11,9 @@ the device from one resident 16 kHz recording; gate rate g = 1.0 (every window g
 the worst case of SURVEY.md §8d).  A step = log-mel of the 1024 windows + stage-1 forward + gate selection +
 stage-2 forward on the selected windows (+ the RCCL all-gather of both logit tables when N > 1).
 Weights are the synthetic "wide" set (no checkpoint exists offline); data and weights are stated in the JSON line.
-The headline `value` is measured in the compute mode that meets the 1e-3 logit tolerance (f16x3); the single-pass fp16
-rate is reported beside it with its measured logit error, never as `value`.
+The headline `value` is measured in a compute mode that meets the 1e-3 logit tolerance: f16c8 (fp16 MFMA pass + one fp8
+pass carrying the split corrections; ~1.5e-4 measured).  The 3-pass f16x3 mode (same tolerance) and the single-pass
+fp16 rate (fails the tolerance) are reported beside it with their measured logit differences, never as `value`.
 """
 import argparse
 import json
@@ -40,8 +41,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step")
     ap.add_argument("--gate-rate", type=float, default=1.0, help="fraction of windows forced through stage 2")
     ap.add_argument("--micro-batch", type=int, default=0, help="0 = library default (auto)")
-    ap.add_argument("--mode", default="f16x3", choices=["f16x3", "f16c8", "f16"])
-    ap.add_argument("--no-fast", action="store_true", help="skip the secondary single-pass fp16 measurement")
+    ap.add_argument("--mode", default="f16c8", choices=["f16c8", "f16x3", "f16"])
+    ap.add_argument("--no-fast", action="store_true", help="skip the secondary f16x3 / single-pass fp16 measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-windows", type=int, default=6)
     args = ap.parse_args()
@@ -146,11 +147,12 @@ def main():
     # measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH correction applied) and
     # committed under profiles/ (same kernel, micro-batch 107)
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")))["kernels"]
+        tr_file = "r01_d_pmc_traffic.json" if args.mode == "f16c8" else "r01_b_pmc_traffic.json"
+        tr = json.load(open(os.path.join(ROOT, "profiles", tr_file)))["kernels"]
         key = {"gemm_fc1": "gemm_fc1(gelu)", "gemm_qkv": "gemm_qkv(store)", "gemm_fc2": "gemm_resid(o,fc2)",
                "gemm_o": "gemm_resid(o,fc2)", "attention": "attention"}[dom]
         roofline["traffic"] = tr[key]["hbm_bytes_per_launch_corrected"]
-        roofline["traffic_source"] = "profiles/r01_b_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
+        roofline["traffic_source"] = f"profiles/{tr_file} (rocprofv3 --pmc, separate passes)"
     except Exception:
         pass
     e2e_flops = value / world * (1.0 + K / B) * FLOP_PER_WINDOW_STAGE
@@ -168,22 +170,25 @@ def main():
                                 "executed_gflop_per_window_stage": executed / (args.steps * (B + K)) / 1e9,
                                 "executed_tflops_per_gpu": executed / dt / 1e12,
                                 "note": "executed = exact last-layer pruning applied (tokens 0/1 only feed the head); "
-                                        "f16x3 issues 3 MFMA passes per GEMM/QK^T FLOP counted here once"},
+                                        "f16c8 issues 2 (f16x3: 3) matrix-pipe passes per GEMM FLOP counted here once"},
         "kernels": roof_all,
     }
 
-    # ---- secondary: single-pass fp16 (fails the 1e-3 tolerance; reported with its measured error) ----
-    if not args.no_fast and args.mode == "f16x3":
+    # ---- secondary: the 3-pass mode (same tolerance) and single-pass fp16 (fails the 1e-3 tolerance), each with its
+    #      measured stage-1 logit difference to the headline mode ----
+    if not args.no_fast and args.mode == "f16c8":
         ref1 = s1_logits.cpu().numpy().copy()
-        m1.set_compute_mode("f16")
-        m2.set_compute_mode("f16")
-        dtf, _ = timed(max(1, args.steps // 2), 1)
-        err = float(np.abs(s1_logits.cpu().numpy() - ref1).max())
-        out["fast_mode"] = {"dtype": "f16", "value": world * B * max(1, args.steps // 2) / dtf, "unit": "windows/s",
-                            "stage1_logit_max_abs_diff_vs_f16x3": err,
-                            "note": "single fp16 MFMA pass; exceeds the 1e-3 logit tolerance, not the headline"}
-        m1.set_compute_mode("f16x3")
-        m2.set_compute_mode("f16x3")
+        nsec = max(1, args.steps // 2)
+        for key, mode, note in (("x3_mode", "f16x3", "(hi,lo) fp16 pairs, 3 MFMA passes; also meets the 1e-3 logit tolerance"),
+                                ("fast_mode", "f16", "single fp16 MFMA pass; exceeds the 1e-3 logit tolerance, not the headline")):
+            m1.set_compute_mode(mode)
+            m2.set_compute_mode(mode)
+            dtf, _ = timed(nsec, 1)
+            err = float(np.abs(s1_logits.cpu().numpy() - ref1).max())
+            out[key] = {"dtype": mode, "value": world * B * nsec / dtf, "unit": "windows/s",
+                        "stage1_logit_max_abs_diff_vs_f16c8": err, "note": note}
+        m1.set_compute_mode(args.mode)
+        m2.set_compute_mode(args.mode)
 
     # ---- BASELINE.json configs[1] as an extra line: batch 256, stage-1 only (log-mel + forward), both modes ----
     if rank == 0 and world == 1:
@@ -197,8 +202,8 @@ def main():
             barrier()
             return n256 * reps / (time.perf_counter() - t0)
         cfg1 = {"workload": "configs[1]: batch=256 windows, stage-1 only (log-mel + AST forward)", "unit": "windows/s"}
-        m1.set_compute_mode("f16x3"); cfg1["f16x3"] = stage1_b256()
-        m1.set_compute_mode("f16"); cfg1["f16"] = stage1_b256()
+        for md in ("f16c8", "f16x3", "f16"):
+            m1.set_compute_mode(md); cfg1[md] = stage1_b256()
         m1.set_compute_mode(args.mode)
         out["config1_stage1_b256"] = cfg1
 
@@ -227,7 +232,7 @@ def main():
                                          f"{tc:.1f} s wall; BLAS threads {blas_threads}, cpus allowed {allowed}, "
                                          f"os.cpu_count {os.cpu_count()} (log-mel part is single-threaded numpy)"}
         out["parity_in_bench"] = {"stage1_logit_max_abs_err_vs_oracle": None}
-        # re-run the parity mode once so the comparison is against f16x3 logits
+        # re-run the headline mode once so the comparison is against its logits
         ctx.logmel(audio, n_samples, 0, hop, win, B)
         ctx.ast_forward(0, None, None, B, s1_logits)
         out["parity_in_bench"]["stage1_logit_max_abs_err_vs_oracle"] = float(

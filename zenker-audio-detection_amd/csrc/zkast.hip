@@ -945,7 +945,10 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   const size_t no = orows * N;
   float *dx, *dw, *dbias, *dres = nullptr, *dpos = nullptr; half_t *xh, *xl, *wh, *wl, *oh = nullptr, *ol = nullptr;
   HIPCHK(c, hipMalloc((void**)&dx, nx * 4)); HIPCHK(c, hipMalloc((void**)&dw, nw * 4)); HIPCHK(c, hipMalloc((void**)&dbias, (size_t)N * 4));
-  HIPCHK(c, hipMalloc((void**)&xh, nx * 2)); HIPCHK(c, hipMalloc((void**)&xl, nx * 2));
+  // x planes are padded to whole 256-row tiles (the ZK_F16C8 kernel stages the M tail unclamped; see gemm_c8.hip)
+  const size_t nxp = nx + (size_t)256 * K;
+  HIPCHK(c, hipMalloc((void**)&xh, nxp * 2)); HIPCHK(c, hipMalloc((void**)&xl, nxp * 2));
+  HIPCHK(c, hipMemset(xh, 0, nxp * 2)); HIPCHK(c, hipMemset(xl, 0, nxp * 2));
   HIPCHK(c, hipMalloc((void**)&wh, nw * 2)); HIPCHK(c, hipMalloc((void**)&wl, nw * 2));
   HIPCHK(c, hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dw, w, nw * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice));

@@ -97,7 +97,7 @@ def build_arg_parser():
     ap.add_argument("--stage2-argmax", action="store_true")
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--dry-run", action="store_true")
-    ap.add_argument("--compute-mode", default="f16x3", choices=["f16", "f16c8", "f16x3"])
+    ap.add_argument("--compute-mode", default="f16c8", choices=["f16", "f16c8", "f16x3"])
     return ap
 
 

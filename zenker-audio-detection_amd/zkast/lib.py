@@ -176,7 +176,7 @@ class Context:
         self._chk(self.lib.zk_synchronize(self.h), "zk_synchronize")
 
     # ---- model ----
-    def load_model(self, stage: int, state_dict: dict, config: dict, fx_mean: float, fx_std: float, compute_mode=ZK_F16X3):
+    def load_model(self, stage: int, state_dict: dict, config: dict, fx_mean: float, fx_std: float, compute_mode=ZK_F16C8):
         descs = (TensorDesc * len(state_dict))()
         keep = []
         for i, (name, arr) in enumerate(state_dict.items()):

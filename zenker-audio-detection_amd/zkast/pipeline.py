@@ -116,7 +116,7 @@ def batch_iter(items, batch_size: int):
 
 
 # ----------------- Model loading -----------------
-def load_stage_model(model_root: str, label_order: List[str], stage: int = 0, compute_mode="f16x3", device: int = 0):
+def load_stage_model(model_root: str, label_order: List[str], stage: int = 0, compute_mode="f16c8", device: int = 0):
     """:86-98.  `stage` picks the library weight slot (0 for the Idle/Swallow model, 1 for Healthy/Zenker)."""
     fx = ZkASTFeatureExtractor.from_pretrained(model_root, device=device)
     config = ZkASTConfig.from_pretrained(model_root)
@@ -316,7 +316,7 @@ def build_arg_parser():
     ap.add_argument("--stage2-argmax", action="store_true")
     ap.add_argument("--output-json")
     ap.add_argument("--show-first-n", type=int, default=5)
-    ap.add_argument("--compute-mode", default="f16x3", choices=["f16", "f16c8", "f16x3"])
+    ap.add_argument("--compute-mode", default="f16c8", choices=["f16", "f16c8", "f16x3"])
     return ap
 
 
