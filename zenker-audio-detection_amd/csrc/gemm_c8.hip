@@ -251,25 +251,42 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
           *(f4_t*)(a.resid + ((size_t)b * ZK_SEQ + 2 + p) * a.N + n) = v + pe;
         }
     } else if constexpr (EPI == ZK_EPI_RESID) {
+      // fp32 residual read-modify-write.  The residual reads of TWO 16-row blocks (8 x 16 B per lane) are issued
+      // together, unguarded (rows clamped to M-1), in front of the LDS transposes that consume them: one exposed HBM
+      // round trip per 32 rows instead of one per 8 (the guarded load -> add -> store chain was latency-bound:
+      // ~49 k cycles per tile, more than a third of the O projection's time).
 #pragma unroll
-      for (int j = 0; j < RM; ++j)
+      for (int jb = 0; jb < RM; jb += 2) {
+        f4_t hv[2][2][2];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-          for (int il = 0; il < 2; ++il) {
-            *(f4_t*)(scr + frow * SCR_STR + il * 64 + fq * 16) = acc[hf * 2 + il][j] + b4[hf * 2 + il];
-            acc[hf * 2 + il][j] = f4_t{0.f, 0.f, 0.f, 0.f};
-          }
+          for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const f4_t v = *(const f4_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
-            const int m = m0 + j * 16 + rd_row + 8 * t;
-            if (m < a.M) {
-              float* dst = a.resid + (size_t)m * a.N + n0 + hf * 32 + rd_ch * 4;
-              *(f4_t*)dst = *(const f4_t*)dst + v;
+            for (int t = 0; t < 2; ++t) {
+              int m = m0 + (jb + jj) * 16 + rd_row + 8 * t;
+              m = m < a.M ? m : a.M - 1;
+              hv[jj][hf][t] = *(const f4_t*)(a.resid + (size_t)m * a.N + n0 + hf * 32 + rd_ch * 4);
+            }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = jb + jj;
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int il = 0; il < 2; ++il) {
+              *(f4_t*)(scr + frow * SCR_STR + il * 64 + fq * 16) = acc[hf * 2 + il][j] + b4[hf * 2 + il];
+              acc[hf * 2 + il][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const f4_t v = *(const f4_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+              const int m = m0 + j * 16 + rd_row + 8 * t;
+              if (m < a.M) *(f4_t*)(a.resid + (size_t)m * a.N + n0 + hf * 32 + rd_ch * 4) = hv[jj][hf][t] + v;
             }
           }
         }
+      }
     } else {
       // STORE (fused QKV): the lo plane stays fp16 — q and k feed the split QK^T of attention.hip.
       // GELU (FC1 -> FC2 operand): the lo plane is the c8 byte pair.
