@@ -89,3 +89,47 @@ def test_batch_driver_end_to_end(tmp_path):
                 assert doc["aggregate"][key] == v
     summ, rows = aggregate.aggregate(out, 0.5)
     assert summ["num_patient_results"] == 2 and {r["gt"] for r in rows} == {"Healthy", "Zenker"}
+
+
+def test_snippet_level_evaluation_loop(tmp_path):
+    """run_inference (analyze_ROC_PR_stage1.py:163-191) and the Trainer.predict contract of
+    test_trained_model_stage1_cv.py at batch 8 over snippets of UNEQUAL length and mixed payload kinds (ndarray,
+    dict at 16 kHz, dict at 48 kHz -> device resampler, WAV path), checked against the CPU oracle."""
+    from zkast import ZkASTConfig, ZkASTFeatureExtractor, ZkASTForAudioClassification, evaluate as ev, pipeline as pl, synth
+    sd = synth.make_ast_weights(41, "wide")
+    mean, std = -1.1509622, 3.5340312
+    mdir = str(tmp_path / "fold0" / "best")
+    _save_model_dir(mdir, sd, mean, std, ["Idle", "Swallow"])
+    lens = [16000, 12000, 16000, 9000, 16000, 16000, 12000, 4000, 16000, 16000, 7000]
+    X, ref_w = [], []
+    for i, n in enumerate(lens):
+        w = synth.synth_recording(100 + i, n)
+        ref_w.append(w)
+        if i % 4 == 1:
+            X.append({"array": w.tolist(), "sampling_rate": 16000})
+        elif i % 4 == 2:
+            path = str(tmp_path / f"s{i}.wav")
+            pl.write_wav_pcm16(path, w, 16000)
+            ref_w[-1] = pl.read_wav(path)[0][0]
+            X.append(path)
+        else:
+            X.append(w)
+    scores = ev.run_inference(mdir, X, batch_size=8)
+    W = orc.ASTWeights(sd)
+    ref = np.concatenate([orc.softmax(orc.ast_forward(orc.extract_features([w], mean, std), W)) for w in ref_w])
+    assert scores.shape == (len(lens),) and scores.dtype == np.float32
+    assert np.abs(scores - ref[:, 1]).max() <= 1e-3
+    # the predict contract: logits in dataset order, argmax + confusion matrix
+    fx = ZkASTFeatureExtractor.from_pretrained(mdir)
+    model = ZkASTForAudioClassification.from_pretrained(mdir, config=ZkASTConfig.from_pretrained(mdir))
+    logits = ev.predict_logits(model, fx, X, batch_size=8)
+    y_true = [int(r[1] > r[0]) for r in ref]
+    y_pred, cm = ev.evaluate_predictions(logits, y_true, 2)
+    assert logits.shape == (len(lens), 2) and y_pred.tolist() == y_true and cm.trace() == len(lens)
+    assert ev.run_inference(mdir, [], 8).shape == (0,)
+    # a 48 kHz dict payload goes through the device resampler
+    w48 = synth.synth_recording(7, 48000)
+    s48 = ev.run_inference(mdir, [{"array": w48, "sampling_rate": 48000}], 8)
+    w16 = orc.resample_sinc_hann(w48, 48000, 16000)
+    r48 = orc.softmax(orc.ast_forward(orc.extract_features([w16], mean, std), W))[0, 1]
+    assert abs(float(s48[0]) - float(r48)) <= 1e-3

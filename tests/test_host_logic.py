@@ -228,3 +228,28 @@ def test_prepare_long_audio_layout(tmp_path):
     assert sr == 48000 and wav.shape == (1, 4800) and np.abs(wav[0] - 0.75 * x).max() <= 1.0 / 32768
     assert any("No long file for specimen: 007_nolong" in str(l) for l in logs)
     assert len(pl.window_audio(wav[0], 0.05, 0.05, 48000)) == 2
+
+
+def test_evaluate_host_helpers(tmp_path):
+    """utils/analyze_ROC_PR_stage1.py:116-160 — split loading with val->test fallback, payload kinds, batching."""
+    from zkast import evaluate as ev
+    x = np.empty(3, dtype=object)
+    x[0] = np.zeros(8000, np.float32); x[1] = {"array": [0.0] * 100, "sampling_rate": 16000}; x[2] = np.ones(5, np.float32)
+    np.save(tmp_path / "test_x_fold2.npy", x, allow_pickle=True)
+    np.save(tmp_path / "test_y_fold2.npy", np.array([0, 1, 1]))
+    X, y, split = ev.load_split(str(tmp_path), 2, "val")
+    assert split == "test" and y == [0, 1, 1] and len(X) == 3
+    with pytest.raises(FileNotFoundError):
+        ev.load_split(str(tmp_path), 3, "val")
+    assert [len(b) for b in ev.batched(list(range(19)), 8)] == [8, 8, 3] and list(ev.batched([], 8)) == []
+    w = ev.to_waveform(X[1])
+    assert w.dtype == np.float32 and w.shape == (100,)
+    assert ev.to_waveform(np.arange(4, dtype=np.float64)).dtype == np.float32
+    with pytest.raises(ValueError):
+        ev.to_waveform({"foo": 1})
+    with pytest.raises(TypeError):
+        ev.to_waveform(3.5)
+    y_pred, cm = ev.evaluate_predictions(np.array([[2.0, 1.0], [0.0, 1.0], [0.5, 0.1]]), [0, 1, 1], 2)
+    assert y_pred.tolist() == [0, 1, 0] and cm.tolist() == [[1, 0], [1, 1]]
+    p = ev.softmax(np.array([[0.0, 0.0], [1.0, 3.0]], np.float32))
+    assert np.allclose(p.sum(1), 1.0) and abs(p[1, 1] - 1 / (1 + np.exp(-2.0))) < 1e-6
