@@ -5,7 +5,7 @@ import numpy as np
 from zkast import lib
 ctx = lib.get_context(0)
 rng = np.random.default_rng(0)
-W = 32
+W = 107
 qkv = rng.normal(0, 1.0, (W * 1214, 2304)).astype(np.float32)
 for ns in (3, 1):
     for _ in range(3):
