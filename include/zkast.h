@@ -135,7 +135,7 @@ int zk_debug_set_tap(zk_ctx* ctx, int32_t layer);
 int zk_debug_get_tap(zk_ctx* ctx, float* out /*host*/, int32_t n_windows);
 
 /* ---- test hooks: run ONE kernel on caller-provided fp32 HOST data (tests/test_kernels_gpu.py) ------------------ */
-/* LayerNorm(768): x (rows,768) -> out (rows,768) = hi (+ lo when nsplit == 3) of the fp16 output planes            */
+/* LayerNorm(768): x (rows,768) -> out (rows,768) = hi (+ lo when nsplit is 3 or 2) of the output planes            */
 int zk_test_layernorm(zk_ctx* ctx, const float* x, const float* gamma, const float* beta, int32_t rows, float eps,
                       int32_t nsplit, float* out);
 /* out = x[M,K] . w[N,K]^T + bias with epilogue epi (0 store, 1 gelu, 2 residual += (out is in/out), 3 patch-embed:
@@ -144,6 +144,10 @@ int zk_test_gemm(zk_ctx* ctx, const float* x, const float* w, const float* bias,
                  int32_t epi, int32_t nsplit, const float* pos, float* out);
 /* qkv (W*1214, 2304) -> out (W*1214, 768): softmax(q k^T / 8) v per head                                            */
 int zk_test_attention(zk_ctx* ctx, const float* qkv, int32_t W, int32_t nsplit, float* out);
+/* the c8 plane of ZK_F16C8 as raw 16-bit entries: activations (is_weight 0): byte 0 = e4m3((x - fp16(x)) * 2^11),
+ * byte 1 = e4m3(x); weights: byte 0 = e4m3(w * 2^w_exp), byte 1 = e4m3((w - fp16(w)) * 2^(w_exp + 11)); OCP e4m3,
+ * round to nearest even, operands clamped to +-448                                                                  */
+int zk_test_split_c8(zk_ctx* ctx, const float* x, int64_t n, int32_t w_exp, int32_t is_weight, uint16_t* out);
 
 #ifdef __cplusplus
 }

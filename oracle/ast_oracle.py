@@ -365,3 +365,41 @@ def resample_sinc_hann(x: np.ndarray, orig_sr: int, new_sr: int, lowpass_filter_
     out = (frames.astype(np.float64) @ kern.T.astype(np.float64)).reshape(-1)        # (frames*new,)
     target = int(np.ceil(new * n / orig))
     return out[:target].astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------------
+# c8 operand planes of the ZK_F16C8 GEMM mode (checker for zk_test_split_c8; format: include/zkast.h)
+# --------------------------------------------------------------------------------------------------
+def fp8_e4m3_bits(x: np.ndarray) -> np.ndarray:
+    """float32 -> OCP e4m3 (bias 7, no infinities, max 448) bit patterns, round to nearest even, inputs clamped to
+    +-448.  Pure integer/floor arithmetic (no float8 dtype needed)."""
+    x = np.clip(np.asarray(x, dtype=np.float64), -448.0, 448.0)
+    sign = (np.signbit(x)).astype(np.uint8) << 7
+    a = np.abs(x)
+    # exponent of the value's binade, clamped to the subnormal binade (2^-6): step = 2^(e-3)
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 2.0 ** -12)))      # zero lands in the subnormal binade
+    e = np.maximum(e, -6.0)
+    step = np.exp2(e - 3.0)
+    q = np.rint(a / step)                         # numpy rint = round half to even
+    # q in [0, 16]: 16 means carry into the next binade
+    carry = q >= 16
+    e = np.where(carry, e + 1, e)
+    q = np.where(carry, 8.0, q)
+    is_sub = (e == -6) & (q < 8)
+    exp_field = np.where(is_sub, 0, e + 7).astype(np.int64)
+    man = np.where(is_sub, q, q - 8).astype(np.int64)
+    return (sign | (exp_field.astype(np.uint8) << 3) | man.astype(np.uint8)).astype(np.uint8)
+
+
+def c8_plane(x: np.ndarray, w_exp: int = 0, is_weight: bool = False) -> np.ndarray:
+    """uint16 entries of the c8 plane: activations (lo8, x8), weights (w8, lo8) — byte 0 is the low byte."""
+    x = np.asarray(x, dtype=np.float32)
+    lo = (x - x.astype(np.float16).astype(np.float32)).astype(np.float32)
+    if is_weight:
+        b0 = fp8_e4m3_bits(x * np.float32(2.0 ** w_exp))
+        b1 = fp8_e4m3_bits(lo * np.float32(2.0 ** (w_exp + 11)))
+    else:
+        b0 = fp8_e4m3_bits(lo * np.float32(2048.0))
+        b1 = fp8_e4m3_bits(x)
+    return b0.astype(np.uint16) | (b1.astype(np.uint16) << 8)

@@ -221,3 +221,17 @@ def test_gemm_c8_wide_dynamic_range(ctx):
     # a row whose values sit below fp8's normal range (2^-6) loses the W-correction for those values only: its error
     # is still no worse than the plain fp16 pass, and absolutely tiny (2^-22 |w| per element)
     assert e2[7].max() <= e1[7].max() * 1.05
+
+
+def test_c8_plane_bytes_bit_exact(ctx):
+    """zk_test_split_c8: the device's c8 operand planes (v_cvt_pk_fp8_f32 after a clamp to +-448) against the oracle's
+    e4m3 encoder, byte for byte — activations and weights, sub-normal range, ties and saturation included."""
+    rng = np.random.default_rng(5)
+    x = (rng.normal(0, 1, 20000) * np.exp(rng.normal(0, 2.5, 20000))).astype(np.float32)
+    x[:8] = [0.0, -0.0, 448.0, -448.0, 1000.0, -3000.0, 2.0 ** -9, 2.0 ** -10]
+    got = ctx.test_split_c8(x)
+    assert np.array_equal(got, orc.c8_plane(x))
+    w = rng.normal(0, 0.03, 20000).astype(np.float32)
+    w[0] = 0.21
+    e = int(np.floor(np.log2(224.0 / np.abs(w).max())))
+    assert np.array_equal(ctx.test_split_c8(w, e, True), orc.c8_plane(w, e, True))

@@ -135,3 +135,18 @@ def test_resample_restatement_properties():
     ref = np.sin(2 * np.pi * 1000.0 * np.arange(16000) / 16000.0)
     assert np.abs(y[200:-200] - ref[200:-200]).max() < 5e-3
     assert orc.resample_sinc_hann(np.zeros(44101, np.float32), 44100, 16000).shape[0] == int(np.ceil(160 * 44101 / 441))
+
+
+def test_fp8_e4m3_encoder_matches_torch_float8():
+    """the oracle's integer-arithmetic e4m3 encoder (checker of the c8 planes) against torch's float8_e4m3fn cast:
+    normals, subnormals, ties, signed zero, saturation."""
+    import torch
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.normal(0, 1, 4000) * np.exp(rng.normal(0, 3, 4000)),
+                        np.array([0.0, -0.0, 448.0, -448.0, 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10, 2.0 ** -6,
+                                  0.0625 + 2.0 ** -8, 17.0, 19.0, 1e-9, 440.0, 464.0 - 1e-3])]).astype(np.float32)
+    x = np.clip(x, -448, 448)
+    ref = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    got = orc.fp8_e4m3_bits(x)
+    assert np.array_equal(got, ref)
+    assert orc.fp8_e4m3_bits(np.array([1e6, -1e6], np.float32)).tolist() == [0x7E, 0xFE]      # clamped to +-448

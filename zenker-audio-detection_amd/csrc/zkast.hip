@@ -1077,4 +1077,18 @@ int zk_test_attention(zk_ctx* c, const float* qkv, int32_t W, int32_t nsplit, fl
   return ZK_OK;
 }
 
+int zk_test_split_c8(zk_ctx* c, const float* x, int64_t n, int32_t w_exp, int32_t is_weight, uint16_t* out) {
+  if (!c || !x || !out || n <= 0) return ZK_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  float* dx; half_t* dc;
+  HIPCHK(c, hipMalloc((void**)&dx, (size_t)n * 4)); HIPCHK(c, hipMalloc((void**)&dc, (size_t)n * 2));
+  HIPCHK(c, hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
+  zk_launch_split_c8(dx, n, w_exp, is_weight, dc, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, dc, (size_t)n * 2, hipMemcpyDeviceToHost));
+  (void)hipFree(dx); (void)hipFree(dc);
+  return ZK_OK;
+}
+
 }  // extern "C"

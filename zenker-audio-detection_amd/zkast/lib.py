@@ -29,7 +29,7 @@ SYMBOLS = [
     "zk_set_micro_batch", "zk_set_prune_last_layer", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_fx",
     "zk_logmel", "zk_features_expand", "zk_features_get", "zk_ast_forward", "zk_softmax", "zk_two_stage", "zk_gate",
     "zk_resample", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_prof_get_flops", "zk_debug_set_tap", "zk_debug_get_tap",
-    "zk_test_layernorm", "zk_test_gemm", "zk_test_attention",
+    "zk_test_layernorm", "zk_test_gemm", "zk_test_attention", "zk_test_split_c8",
 ]
 
 
@@ -100,6 +100,7 @@ def load_library() -> C.CDLL:
             "zk_debug_set_tap": (C.c_int, [vp, i32]),
             "zk_debug_get_tap": (C.c_int, [vp, vp, i32]),
             "zk_test_layernorm": (C.c_int, [vp, vp, vp, vp, i32, f32, i32, vp]),
+            "zk_test_split_c8": (C.c_int, [vp, vp, C.c_int64, i32, i32, vp]),
             "zk_test_gemm": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
             "zk_test_attention": (C.c_int, [vp, vp, i32, i32, vp]),
         }
@@ -344,6 +345,13 @@ class Context:
         self._chk(self.lib.zk_test_gemm(self.h, x.ctypes.data, w.ctypes.data, bias.ctypes.data, M, N, K, int(epi),
                                         int(nsplit), None if pos is None else pos.ctypes.data, out.ctypes.data),
                   "zk_test_gemm")
+        return out
+
+    def test_split_c8(self, x, w_exp=0, is_weight=False):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1)
+        out = np.empty(x.size, np.uint16)
+        self._chk(self.lib.zk_test_split_c8(self.h, x.ctypes.data, x.size, int(w_exp), int(bool(is_weight)),
+                                            out.ctypes.data), "zk_test_split_c8")
         return out
 
     def test_attention(self, qkv, n_windows, nsplit):
