@@ -174,7 +174,22 @@ def _gelu(x):
 
 
 def _lin(x, w, b, quant):
+    if quant == "f16c8":
+        return _lin_f16c8(x, w, b)
     return _q(x, quant) @ _q(w, quant).T + b
+
+
+def _lin_f16c8(x, w, b):
+    """What the ZK_F16C8 GEMM computes (gemm_c8.hip): fp16 product + the two split corrections in e4m3,
+    x·w = xh·wh + [fp8(xl·2^11)·fp8(w·2^e) + fp8(x)·fp8(wl·2^(e+11))]·2^-(e+11), fp32 accumulation."""
+    x = np.asarray(x, np.float32); w = np.asarray(w, np.float32)
+    xh = x.astype(np.float16).astype(np.float32); wh = w.astype(np.float16).astype(np.float32)
+    wmax = float(np.abs(w).max())
+    e = int(np.floor(np.log2(224.0 / wmax))) if wmax > 0 else 0
+    x8 = fp8_e4m3_round(x); xl8 = fp8_e4m3_round((x - xh) * np.float32(2048.0))
+    w8 = fp8_e4m3_round(w * np.float32(2.0 ** e)); wl8 = fp8_e4m3_round((w - wh) * np.float32(2.0 ** (e + 11)))
+    corr = (xl8 @ w8.T + x8 @ wl8.T) * np.float32(2.0 ** -(e + 11))
+    return xh @ wh.T + corr + b
 
 
 class ASTWeights:
@@ -223,7 +238,7 @@ def embed(input_values: np.ndarray, W: ASTWeights, quant=None) -> np.ndarray:
     ti = (np.arange(T_OUT) * TSTRIDE)[:, None] + np.arange(PATCH)[None, :]   # (101,16)
     patches = x[:, fi[:, None, :, None], ti[None, :, None, :]]               # (B,12,101,16,16)
     patches = patches.reshape(B, F_OUT * T_OUT, PATCH * PATCH)
-    emb = _q(patches, quant) @ _q(cw, quant).T + cb       # token = f*101 + t
+    emb = _lin(patches, cw, cb, quant)                     # token = f*101 + t
     cls = np.broadcast_to(W.g(p + "cls_token"), (B, 1, HIDDEN))
     dist = np.broadcast_to(W.g(p + "distillation_token"), (B, 1, HIDDEN))
     h = np.concatenate([cls, dist, emb], axis=1) + W.g(p + "position_embeddings")
@@ -236,11 +251,13 @@ def encoder_layer(h: np.ndarray, L: dict, quant=None) -> np.ndarray:
     q = _lin(x, *L["q"], quant).reshape(B, S, HEADS, HEAD_DIM).transpose(0, 2, 1, 3)
     k = _lin(x, *L["k"], quant).reshape(B, S, HEADS, HEAD_DIM).transpose(0, 2, 1, 3)
     v = _lin(x, *L["v"], quant).reshape(B, S, HEADS, HEAD_DIM).transpose(0, 2, 1, 3)
-    s = (_q(q, quant) @ _q(k, quant).transpose(0, 1, 3, 2)) * np.float32(HEAD_DIM ** -0.5)
+    aq = None if quant == "f16c8" else quant        # f16c8: QK^T is a 3-term fp16 split (fp32-grade), P.V one fp16 pass
+    s = (_q(q, aq) @ _q(k, aq).transpose(0, 1, 3, 2)) * np.float32(HEAD_DIM ** -0.5)
     s = s - s.max(-1, keepdims=True)
     e = np.exp(s)
     pr = e / e.sum(-1, keepdims=True)
-    a = (_q(pr, quant) @ _q(v, quant)).transpose(0, 2, 1, 3).reshape(B, S, HIDDEN)
+    pq = "f16" if quant == "f16c8" else quant
+    a = (_q(pr, pq) @ _q(v, pq)).transpose(0, 2, 1, 3).reshape(B, S, HIDDEN)
     h = h + _lin(a, *L["o"], quant)
     x = _ln(h, *L["ln2"])
     m = _gelu(_lin(x, *L["fc1"], quant))
@@ -390,6 +407,20 @@ def fp8_e4m3_bits(x: np.ndarray) -> np.ndarray:
     exp_field = np.where(is_sub, 0, e + 7).astype(np.int64)
     man = np.where(is_sub, q, q - 8).astype(np.int64)
     return (sign | (exp_field.astype(np.uint8) << 3) | man.astype(np.uint8)).astype(np.uint8)
+
+
+_E4M3_LUT = None
+
+
+def fp8_e4m3_round(x: np.ndarray) -> np.ndarray:
+    """x rounded to the nearest e4m3 value (clamped to +-448), as float32."""
+    global _E4M3_LUT
+    if _E4M3_LUT is None:
+        b = np.arange(256)
+        s_, e_, m_ = b >> 7, (b >> 3) & 15, b & 7
+        v = np.where(e_ == 0, m_ * 2.0 ** -9, (8 + m_) * np.exp2(e_ - 10.0))
+        _E4M3_LUT = np.where(s_ == 1, -v, v).astype(np.float32)
+    return _E4M3_LUT[fp8_e4m3_bits(x)]
 
 
 def c8_plane(x: np.ndarray, w_exp: int = 0, is_weight: bool = False) -> np.ndarray:

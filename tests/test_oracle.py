@@ -150,3 +150,18 @@ def test_fp8_e4m3_encoder_matches_torch_float8():
     got = orc.fp8_e4m3_bits(x)
     assert np.array_equal(got, ref)
     assert orc.fp8_e4m3_bits(np.array([1e6, -1e6], np.float32)).tolist() == [0x7E, 0xFE]      # clamped to +-448
+
+
+def test_f16c8_arithmetic_emulation_meets_tolerance(G):
+    """CPU statement of what the default compute mode does to the numbers (oracle quant="f16c8": fp16 products + e4m3
+    split corrections, fp16 P.V): its logits stay within the 1e-3 tolerance of the transformers fp32 golden logits, and
+    well inside what a plain fp16 pass gives."""
+    from zkast import synth
+    g, fb = G["model"], G["fbank"]
+    feats = orc.extract_features(synth.golden_windows()[[0, 1]], float(fb["mean"]), float(fb["std"]))
+    W = orc.ASTWeights(synth.make_ast_weights(11, "wide"))
+    ref = g["wide_logits"][:2]
+    e8 = np.abs(orc.ast_forward(feats, W, quant="f16c8") - ref).max()
+    e1 = np.abs(orc.ast_forward(feats, W, quant="f16") - ref).max()
+    print(f"oracle emulation, wide set: f16c8 {e8:.2e}, single fp16 pass {e1:.2e}")
+    assert e8 <= 5e-4 and e8 * 4 <= e1
