@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
     return (const char*)(((unsigned long long)hi << 32) | lo);
   };
+  // The loads name the GLOBAL address space: a pointer rebuilt from readfirstlane'd integers is otherwise generic and
+  // hipcc emits flat_load, which also counts in lgkmcnt — every wait for a K/V fragment read of the CURRENT tile then
+  // waits for the HBM round trip of the NEXT tile's prefetch.
+  typedef __attribute__((address_space(1))) h8_t GLOBAL_H8;
   auto load_tile = [&](int kt) {
     if (kt == NKT - 1) set_offs(kt);
     const size_t tb = ((tok0 + (size_t)kt * KT) * QKV_LD + head * ZK_HEAD_DIM) * 2;     // bytes
@@ -108,12 +112,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     const char* gv = uniform_ptr((const char*)qkv_hi + tb + 2 * ZK_HIDDEN * 2);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      pk[0][u] = *(const h8_t*)(gk + toff[u]);
+      pk[0][u] = *(const GLOBAL_H8*)(gk + toff[u]);
       if constexpr (SPLIT) {
         const char* gl = uniform_ptr((const char*)qkv_lo + tb + ZK_HIDDEN * 2);
-        pk[1][u] = *(const h8_t*)(gl + toff[u]);
+        pk[1][u] = *(const GLOBAL_H8*)(gl + toff[u]);
       }
-      pk[NIMG - 1][u] = *(const h8_t*)(gv + toff[u]);
+      pk[NIMG - 1][u] = *(const GLOBAL_H8*)(gv + toff[u]);
     }
   };
   auto store_tile = [&](int buf) {
