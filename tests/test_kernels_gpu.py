@@ -235,3 +235,27 @@ def test_c8_plane_bytes_bit_exact(ctx):
     w[0] = 0.21
     e = int(np.floor(np.log2(224.0 / np.abs(w).max())))
     assert np.array_equal(ctx.test_split_c8(w, e, True), orc.c8_plane(w, e, True))
+
+
+def test_gemm_c8_exact_integers_many_shapes(ctx):
+    """stress of the hand-scheduled ZK_F16C8 kernel (inline-asm fragment reads with hand-counted waits, LDS-DMA ring,
+    deferred tile, persistent tile walk): 24 ragged shapes with small-integer operands — every product and sum is
+    exact in fp16 / e4m3 / fp32, so ANY stale fragment, missed wait or mis-ordered slot shows up as a non-zero
+    difference.  Includes M < 256, M spanning several persistent rounds, and all three K of the model."""
+    from zkast import lib
+    rng = np.random.default_rng(123)
+    shapes = [(1, 768, 768), (255, 768, 256), (256, 2304, 768), (257, 3072, 768), (700, 768, 3072)]
+    for _ in range(19):
+        shapes.append((int(rng.integers(1, 3000)), int(rng.choice([768, 2304, 3072])), int(rng.choice([256, 768, 3072]))))
+    shapes.append((70000, 768, 768))                     # > 256 tiles per column block: several rounds per workgroup
+    for (M, N, K) in shapes:
+        x = rng.integers(-2, 3, (M, K)).astype(np.float32)
+        w = rng.integers(-2, 3, (N, K)).astype(np.float32)
+        bias = rng.integers(-8, 9, (N,)).astype(np.float32)
+        ref = x.astype(np.float64) @ w.astype(np.float64).T + bias
+        r0 = rng.integers(-50, 50, (M, N)).astype(np.float32)
+        out = ctx.test_gemm(x, w, bias, lib.EPI_RESID, 2, resid=r0)
+        assert np.array_equal(out, ref + r0), (M, N, K)
+        if M <= 1000:
+            out = ctx.test_gemm(x, w, bias, lib.EPI_STORE, 2)
+            assert np.array_equal(out, ref), (M, N, K)
