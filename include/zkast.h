@@ -119,6 +119,13 @@ int zk_gate(zk_ctx* ctx, const float* logits, int32_t n, float thr1, float fwd_m
 int zk_resample(zk_ctx* ctx, const float* in /*host|device*/, int64_t n_in, int32_t orig_sr, int32_t new_sr,
                 float* out /*host|device*/, int64_t n_out);
 
+/* torchaudio.load + wav.mean(dim=0) (src/test_long_audio_windows_2stage.py:54-56) for the sample data of a RIFF/WAVE
+ * "data" chunk (the header is parsed by the caller): interleaved little-endian samples -> mono float32, n_frames =
+ * n_bytes / (channels * bits/8).  format_tag 1 = integer PCM (bits 8 / 16 / 24 / 32), 3 = IEEE float (bits 32 / 64);
+ * scaling x / 2^(bits-1) (8-bit: (x - 128) / 128).  out holds n_frames floats.                                     */
+int zk_wav_decode(zk_ctx* ctx, const void* data /*host|device*/, int64_t n_bytes, int32_t format_tag, int32_t bits,
+                  int32_t channels, float* out /*host|device*/);
+
 /* ---- introspection / measurement ---------------------------------------------------------------------------- */
 /* per-kernel-class HIP-event timing over the calls made since zk_prof_begin (on the context's stream).
  * zk_prof_get: name in {"gemm_qkv","gemm_o","gemm_fc1","gemm_fc2","gemm_patch","attention","layernorm","logmel",

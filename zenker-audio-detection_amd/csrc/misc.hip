@@ -43,6 +43,43 @@ __global__ __launch_bounds__(256) void split_c8_kernel(const float* __restrict__
   out[i] = (unsigned short)__builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8(b0), zk_clamp_fp8(b1), 0, false);
 }
 
+// WAV sample decode + channel mean (load_audio, src/test_long_audio_windows_2stage.py:54-56): interleaved little-endian
+// samples -> one mono float32 per frame.  fmt: 1 = integer PCM (8 unsigned / 16 / 24 / 32 bit), 3 = IEEE float (32 / 64).
+// Scaling as torchaudio.load(normalize=True): x / 2^(bits-1) (8-bit: (x-128)/128); channel mean = fp32 sum in channel
+// order divided by the channel count (what wav.mean(dim=0) does for a handful of channels).
+__global__ __launch_bounds__(256) void wav_decode_kernel(const unsigned char* __restrict__ raw, int64_t n_frames, int fmt,
+                                                         int bits, int channels, float* __restrict__ out) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= n_frames) return;
+  const int bps = bits >> 3;
+  const unsigned char* p = raw + (size_t)f * channels * bps;
+  float acc = 0.f;
+  for (int c = 0; c < channels; ++c, p += bps) {
+    float v;
+    if (fmt == 3) {
+      if (bits == 32) { unsigned u = p[0] | (p[1] << 8) | (p[2] << 16) | ((unsigned)p[3] << 24); v = __uint_as_float(u); }
+      else {
+        unsigned long long u = 0;
+        for (int b = 7; b >= 0; --b) u = (u << 8) | p[b];
+        v = (float)__longlong_as_double((long long)u);
+      }
+    } else if (bits == 16) {
+      v = (float)(short)(p[0] | (p[1] << 8)) * (1.0f / 32768.0f);
+    } else if (bits == 8) {
+      v = ((float)p[0] - 128.0f) * (1.0f / 128.0f);
+    } else if (bits == 24) {
+      int x = p[0] | (p[1] << 8) | (p[2] << 16);
+      x = (x ^ 0x800000) - 0x800000;
+      v = (float)x * (1.0f / 8388608.0f);
+    } else {
+      const int x = (int)(p[0] | (p[1] << 8) | (p[2] << 16) | ((unsigned)p[3] << 24));
+      v = (float)((double)x / 2147483648.0);
+    }
+    acc = c == 0 ? v : acc + v;
+  }
+  out[f] = channels > 1 ? acc / (float)channels : acc;
+}
+
 // out[i*neu + p] = sum_j kernels[p][j] * padded[i*orig + j],  padded = zeros(width) ++ in ++ zeros(width+orig)
 // (torchaudio.functional._apply_sinc_resample_kernel: conv1d with stride=orig over the padded waveform).
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, int64_t n_in, int orig, int neu,
@@ -84,4 +121,11 @@ void zk_launch_split_c8(const float* src, int64_t n, int w_exp, int is_weight, h
   const float s_lo = ldexpf(1.0f, (is_weight ? w_exp : 0) + ZK_C8_SHIFT);
   hipLaunchKernelGGL(split_c8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, n, s_main, s_lo, is_weight,
                      (unsigned short*)c8);
+}
+
+void zk_launch_wav_decode(const unsigned char* raw, int64_t n_frames, int fmt, int bits, int channels, float* out,
+                          hipStream_t s) {
+  if (n_frames <= 0) return;
+  hipLaunchKernelGGL(wav_decode_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, s, raw, n_frames, fmt, bits,
+                     channels, out);
 }

@@ -115,6 +115,8 @@ void zk_launch_gate(const float* logits, int n, float thr1, float fwd_min_prob, 
 void zk_launch_softmax2(const float* logits, int n, int num_labels, float* probs, hipStream_t s);
 void zk_launch_resample(const float* in, int64_t n_in, int orig, int neu, int width, const float* kernels,
                         int klen, float* out, int64_t n_out, hipStream_t s);
+void zk_launch_wav_decode(const unsigned char* raw, int64_t n_frames, int fmt, int bits, int channels, float* out,
+                          hipStream_t s);
 void zk_launch_split_f32(const float* src, int64_t n, float scale, half_t* hi, half_t* lo, hipStream_t s);
 // weights: c8 plane = (fp8(w·2^e), fp8((w - fp16(w))·2^(e+11))) byte pairs; activations (is_weight = 0): (fp8((x-xh)·2^11), fp8(x))
 void zk_launch_split_c8(const float* src, int64_t n, int w_exp, int is_weight, half_t* c8, hipStream_t s);

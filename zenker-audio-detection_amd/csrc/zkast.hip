@@ -818,6 +818,27 @@ int zk_two_stage(zk_ctx* c, const float* audio, int64_t n_samples, int64_t first
   return ZK_OK;
 }
 
+int zk_wav_decode(zk_ctx* c, const void* data, int64_t n_bytes, int32_t format_tag, int32_t bits, int32_t channels, float* out) {
+  if (!c || !data || !out) return ZK_E_ARG;
+  const bool ok = (format_tag == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32)) ||
+                  (format_tag == 3 && (bits == 32 || bits == 64));
+  if (!ok) return fail(c, ZK_E_ARG, "unsupported WAVE sample format: tag %d, %d bits", format_tag, bits);
+  if (channels < 1 || channels > 64 || n_bytes < 0) return fail(c, ZK_E_ARG, "bad channel count / size");
+  const int64_t n_frames = n_bytes / ((int64_t)channels * (bits / 8));
+  if (n_frames == 0) return ZK_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void* d_in = nullptr;
+  int rc = to_device(c, data, (size_t)n_frames * channels * (bits / 8), c->st_in, &d_in);
+  if (rc) return rc;
+  const bool dev = is_device_ptr(out);
+  float* d_out = out;
+  if (!dev) { HIPCHK(c, c->st_out.ensure((size_t)n_frames * 4)); d_out = c->st_out.as<float>(); }
+  zk_launch_wav_decode((const unsigned char*)d_in, n_frames, format_tag, bits, channels, d_out, c->stream);
+  HIPCHK(c, hipGetLastError());
+  if (!dev) return from_device(c, d_out, out, (size_t)n_frames * 4);
+  return finish(c);
+}
+
 int zk_resample(zk_ctx* c, const float* in, int64_t n_in, int32_t orig_sr, int32_t new_sr, float* out, int64_t n_out) {
   if (!c || !in || !out) return ZK_E_ARG;
   if (orig_sr <= 0 || new_sr <= 0 || n_in <= 0) return fail(c, ZK_E_ARG, "bad resample arguments");

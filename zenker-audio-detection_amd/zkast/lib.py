@@ -28,7 +28,7 @@ SYMBOLS = [
     "zk_create", "zk_destroy", "zk_last_error", "zk_set_stream", "zk_set_async", "zk_synchronize",
     "zk_set_micro_batch", "zk_set_prune_last_layer", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_fx",
     "zk_logmel", "zk_features_expand", "zk_features_get", "zk_ast_forward", "zk_softmax", "zk_two_stage", "zk_gate",
-    "zk_resample", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_prof_get_flops", "zk_debug_set_tap", "zk_debug_get_tap",
+    "zk_resample", "zk_wav_decode", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_prof_get_flops", "zk_debug_set_tap", "zk_debug_get_tap",
     "zk_test_layernorm", "zk_test_gemm", "zk_test_attention", "zk_test_split_c8",
 ]
 
@@ -99,6 +99,7 @@ def load_library() -> C.CDLL:
             "zk_prof_get_flops": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double)]),
             "zk_debug_set_tap": (C.c_int, [vp, i32]),
             "zk_debug_get_tap": (C.c_int, [vp, vp, i32]),
+            "zk_wav_decode": (C.c_int, [vp, vp, i64, i32, i32, i32, vp]),
             "zk_test_layernorm": (C.c_int, [vp, vp, vp, vp, i32, f32, i32, vp]),
             "zk_test_split_c8": (C.c_int, [vp, vp, C.c_int64, i32, i32, vp]),
             "zk_test_gemm": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
@@ -295,6 +296,16 @@ class Context:
         out = np.empty((n_out,), np.float32)
         self._chk(self.lib.zk_resample(self.h, audio.ctypes.data, audio.shape[0], int(orig_sr), int(new_sr),
                                        out.ctypes.data, n_out), "zk_resample")
+        return out
+
+    def wav_decode(self, raw: bytes, format_tag: int, bits: int, channels: int) -> np.ndarray:
+        """sample bytes of a WAVE data chunk -> mono float32 (channel mean), decoded on the GPU"""
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        n_frames = buf.size // (channels * (bits // 8))
+        out = np.empty((n_frames,), np.float32)
+        if n_frames:
+            self._chk(self.lib.zk_wav_decode(self.h, buf.ctypes.data, buf.size, int(format_tag), int(bits), int(channels),
+                                             out.ctypes.data), "zk_wav_decode")
         return out
 
     # ---- measurement ----

@@ -22,11 +22,9 @@ SAMPLING_RATE = 16000
 
 
 # ----------------- Audio helpers -----------------
-def read_wav(path: str) -> Tuple[np.ndarray, int]:
-    """Minimal RIFF/WAVE reader (PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE) ->
-    (channels, frames) float32 in [-1, 1], sample rate.  Stands in for torchaudio.load
-    (src/test_long_audio_windows_2stage.py:54); the files it reads are written by utils/PrepareDatasetLongAudio.py:59-67
-    (soundfile, mono PCM_16, native rate)."""
+def parse_wav(path: str):
+    """RIFF/WAVE container walk -> (format_tag, channels, sample_rate, bits, sample_bytes).  PCM 8/16/24/32-bit, IEEE float
+    32/64, WAVE_FORMAT_EXTENSIBLE."""
     with open(path, "rb") as f:
         data = f.read()
     if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
@@ -46,9 +44,20 @@ def read_wav(path: str) -> Tuple[np.ndarray, int]:
     if fmt is None or raw is None:
         raise ValueError(f"{path}: missing fmt/data chunk")
     tag, ch, sr, bits = fmt
+    if not ((tag == 1 and bits in (8, 16, 24, 32)) or (tag == 3 and bits in (32, 64))):
+        raise ValueError(f"{path}: unsupported WAVE format tag {tag} / {bits} bits")
+    return tag, ch, sr, bits, raw
+
+
+def read_wav(path: str) -> Tuple[np.ndarray, int]:
+    """Minimal RIFF/WAVE reader (host, numpy) -> (channels, frames) float32 in [-1, 1], sample rate.  Stands in for
+    torchaudio.load (src/test_long_audio_windows_2stage.py:54); the files it reads are written by
+    utils/PrepareDatasetLongAudio.py:59-67 (soundfile, mono PCM_16, native rate).  The product path decodes on the GPU
+    (load_audio -> zk_wav_decode); this host version is what the dataset-preparation helper and the tests use."""
+    tag, ch, sr, bits, raw = parse_wav(path)
     if tag == 1:
         if bits == 16:
-            x = np.frombuffer(raw, "<i2").astype(np.float32) / 32768.0
+            x = np.frombuffer(raw[: len(raw) // 2 * 2], "<i2").astype(np.float32) / 32768.0
         elif bits == 8:
             x = (np.frombuffer(raw, np.uint8).astype(np.float32) - 128.0) / 128.0
         elif bits == 24:
@@ -56,14 +65,10 @@ def read_wav(path: str) -> Tuple[np.ndarray, int]:
             v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
             v = np.where(v >= 1 << 23, v - (1 << 24), v)
             x = v.astype(np.float32) / float(1 << 23)
-        elif bits == 32:
-            x = (np.frombuffer(raw, "<i4").astype(np.float64) / float(1 << 31)).astype(np.float32)
         else:
-            raise ValueError(f"{path}: unsupported PCM width {bits}")
-    elif tag == 3:
-        x = np.frombuffer(raw, "<f4" if bits == 32 else "<f8").astype(np.float32)
+            x = (np.frombuffer(raw[: len(raw) // 4 * 4], "<i4").astype(np.float64) / float(1 << 31)).astype(np.float32)
     else:
-        raise ValueError(f"{path}: unsupported WAVE format tag {tag}")
+        x = np.frombuffer(raw[: len(raw) // (bits // 8) * (bits // 8)], "<f4" if bits == 32 else "<f8").astype(np.float32)
     n = x.shape[0] // ch
     return np.ascontiguousarray(x[: n * ch].reshape(n, ch).T), sr
 
@@ -77,13 +82,13 @@ def write_wav_pcm16(path: str, audio: np.ndarray, sr: int):
 
 
 def load_audio(path: str, target_sr: int = SAMPLING_RATE, device: int = 0) -> np.ndarray:
-    """src/test_long_audio_windows_2stage.py:53-59: load, mean over channels, resample to 16 kHz (on the GPU)."""
-    wav, sr = read_wav(path)
-    if wav.shape[0] > 1:
-        wav = wav.mean(axis=0, keepdims=True)
-    x = np.ascontiguousarray(wav[0], dtype=np.float32)
+    """src/test_long_audio_windows_2stage.py:53-59: load, mean over channels, resample to 16 kHz — sample decode,
+    channel mean and resampling all run on the GPU (zk_wav_decode, zk_resample); only the RIFF header is walked here."""
+    tag, ch, sr, bits, raw = parse_wav(path)
+    ctx = _lib.get_context(device)
+    x = ctx.wav_decode(raw, tag, bits, ch)
     if sr != target_sr:
-        x = _lib.get_context(device).resample(x, sr, target_sr)
+        x = ctx.resample(x, sr, target_sr)
     return x
 
 
