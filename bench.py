@@ -147,7 +147,7 @@ def main():
     # measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH correction applied) and
     # committed under profiles/ (same kernel, micro-batch 107)
     try:
-        tr_file = "r01_e_pmc_traffic.json" if args.mode == "f16c8" else "r01_b_pmc_traffic.json"
+        tr_file = "r01_f_pmc_traffic.json" if args.mode == "f16c8" else "r01_b_pmc_traffic.json"
         tr = json.load(open(os.path.join(ROOT, "profiles", tr_file)))["kernels"]
         key = {"gemm_fc1": "gemm_fc1(gelu)", "gemm_qkv": "gemm_qkv(store)", "gemm_fc2": "gemm_resid(o,fc2)",
                "gemm_o": "gemm_resid(o,fc2)", "attention": "attention"}[dom]
