@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   for (int i = 0; i < 16; ++i) negm[i] = 0.f;
   float m_run = 0.f, l_run = 0.f;
 
+  const bool wave_active = __builtin_amdgcn_readfirstlane(qt * QT + wave * 32) < S_;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -167,6 +168,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     const char* kb_base = smem + cur * BUF_B;
     const char* vb_base = kb_base + (NIMG - 1) * TILE_B;
 
+    // a wave whose 32 query rows all lie beyond the sequence (the last query tile holds 62 of 128 rows: waves 2 and 3)
+    // only takes part in the K/V staging and the barriers — its SIMD time goes to the other resident workgroup
+    if (wave_active) {
     // ---- scores minus running max: two 32-key blocks ----
     f16_t sacc[2];
 #pragma unroll
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
           const h8_t vt = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
           oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt, pf[kb][s], oacc[mb], 0, 0, 0);
         }
+    }   // wave_active
 
     if (kt + 1 < NKT) store_tile(cur ^ 1);
     __syncthreads();
