@@ -177,6 +177,32 @@ def test_aggregate_matches_reference(BA, tmp_path):
     assert agg.infer_ground_truth([]) == "Unknown" and agg.parse_patient_id("/x/006_2stage.json") == "006"
 
 
+def test_aggregate_cli_writes_csv_and_json(BA, tmp_path, capsys):
+    """`python -m zkast.aggregate` flags of utils/aggregate_2stage_results.py:240-266: summary on stdout, --store-output
+    default file names inside the outputs directory, explicit --csv / --json paths win, header = the reference's row."""
+    import csv
+    from zkast import aggregate as agg
+    for pid, doc in BA["agg_inputs"].items():
+        json.dump(doc, open(tmp_path / f"{pid}_2stage.json", "w"))
+    json.dump({"x": 1}, open(tmp_path / "batch_fold1_2stage.json", "w"))      # counted as found, never as a patient
+    summ = agg.main(["--outputs-dir", str(tmp_path), "--threshold", "0.3", "--store-output", "--verbose"])
+    out = capsys.readouterr().out
+    printed = json.loads(out[: out.index("[INFO]")])
+    exp = dict(BA["agg_expected"]["0.3"])
+    printed.pop("outputs_dir")
+    assert printed == exp and summ["threshold"] == 0.3
+    rows = list(csv.DictReader(open(tmp_path / "per_patient_results.csv")))
+    assert list(rows[0].keys()) == agg.ROW_FIELDS and len(rows) == exp["num_patient_results"]
+    doc = json.load(open(tmp_path / "aggregate_summary.json"))
+    assert set(doc) == {"summary", "patients"} and len(doc["patients"]) == len(rows)
+    assert {k: doc["summary"][k] for k in exp} == exp
+    # the written files are not mistaken for patient results on a second run; explicit paths win over the defaults
+    c2, j2 = tmp_path / "x.csv", tmp_path / "x.json"
+    agg.main(["--outputs-dir", str(tmp_path), "--csv", str(c2), "--json", str(j2)])
+    assert c2.exists() and j2.exists()
+    assert json.load(open(j2))["summary"]["num_patient_results"] == exp["num_patient_results"]
+
+
 def test_batch_skip_dry_run_and_error_isolation(tmp_path):
     from zkast import batch
     out = tmp_path / "out"

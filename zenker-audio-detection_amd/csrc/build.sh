@@ -1,5 +1,7 @@
 #!/usr/bin/env bash
 # Build libzkast.so for gfx950 (cross-compiles without a GPU).  Output: ../zkast/libzkast.so
+# ZK_PROBES=1 additionally links ../zkast/libzkast_probes.so = the same objects + the tools/ probes (probe.hip and
+# kernel variants kept for A/B timing); the product library never contains probe code.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../zkast"
@@ -10,8 +12,13 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950 has a unified file); without it hipcc parks
 # them in AGPRs and the attention softmax pays ~150 v_accvgpr_read/write per key tile.
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
+PRODUCT="gemm gemm_c8 attention layernorm embed head logmel misc comm zkast"
+PROBES="gemm_c8_v1 probe"
+SRCS="$PRODUCT"
+[ "${ZK_PROBES:-0}" = "1" ] && SRCS="$PRODUCT $PROBES"
 pids=()
-for f in gemm gemm_c8 attention layernorm embed head logmel misc zkast; do
+for f in $SRCS; do
+  [ -f "$HERE/$f.hip" ] || continue
   if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/zk_common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/gemm_util.h" -nt "$OBJ/$f.o" ] \
      || [ "$HERE/../../include/zkast.h" -nt "$OBJ/$f.o" ]; then
     EXTRA=""
@@ -23,5 +30,13 @@ for f in gemm gemm_c8 attention layernorm embed head logmel misc zkast; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIBNAME" "$OBJ"/{gemm,gemm_c8,attention,layernorm,embed,head,logmel,misc,zkast}.o
+objs=()
+for f in $PRODUCT; do [ -f "$OBJ/$f.o" ] && objs+=("$OBJ/$f.o"); done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIBNAME" "${objs[@]}" ${ZK_LINK_LIBS:-}
 echo "built $OUT/$LIBNAME"
+if [ "${ZK_PROBES:-0}" = "1" ]; then
+  pobjs=("${objs[@]}")
+  for f in $PROBES; do [ -f "$OBJ/$f.o" ] && pobjs+=("$OBJ/$f.o"); done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${ZK_PROBES_NAME:-libzkast_probes.so}" "${pobjs[@]}" ${ZK_LINK_LIBS:-}
+  echo "built $OUT/${ZK_PROBES_NAME:-libzkast_probes.so}"
+fi

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
     const int jb = c / RN, i = c % RN;
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-      if (j < npieces && piece0 + j < LPT && !(a.ablate & 1)) issue_piece(piece0 + j);
+      if (j < npieces && piece0 + j < LPT) issue_piece(piece0 + j);
       if constexpr (NPL == 2) {
         acc[i][jb * JB + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc_l, xc_h[j], acc[i][jb * JB + j], 0, 0, 0);
         acc[i][jb * JB + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc_h, xc_l[j], acc[i][jb * JB + j], 0, 0, 0);
@@ -277,31 +277,15 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
   };
 
   if (total == 0) return;
-  const bool stamp = a.stamps != nullptr && tid == 0;
-  long long* st = a.stamps + (size_t)blockIdx.x * 16;
-  if (stamp) { st[0] = (long long)__builtin_amdgcn_s_memtime(); st[14] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
   for (int i = 0; i < NST - 1; ++i)
     if (l_step < total) issue();
   // first step landed?  (conservative: drain; happens once per launch)
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
-  if (stamp) st[1] = (long long)__builtin_amdgcn_s_memtime();
 
   int c_k = 0;
   bool epi_pending = false;
-  const bool fine = a.stamps != nullptr && (a.ablate & 8) && lane == 0 && (wave == 0 || wave == 4);
-  long long fs[5] = {0, 0, 0, 0, 0};
-  long long ft = 0;
-#define ZK_FINE(idx)                                                         \
-  if (fine) {                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                       \
-    const long long now__ = (long long)__builtin_amdgcn_s_memtime();        \
-    fs[idx] += now__ - ft;                                                   \
-    ft = now__;                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                       \
-  }
-  if (fine) ft = (long long)__builtin_amdgcn_s_memtime();
   for (int c_step = 0; c_step < total; ++c_step) {
     const char* xb = smem + (c_step % NST) * STAGE;
     const char* wb = xb + NPL * XBYTES;
@@ -312,14 +296,11 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
     if (c_step > 0) {
       mfma_chunk(NCH - 1, 0, 0);
       if (epi_pending) {
-        if (stamp && c_ord < 2) st[2 + 2 * c_ord] = (long long)__builtin_amdgcn_s_memtime();
         epilogue();
-        if (stamp && c_ord <= 2) st[1 + 2 * c_ord] = (long long)__builtin_amdgcn_s_memtime();
         epi_pending = false;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    ZK_FINE(0)
 #pragma unroll
     for (int j = 0; j < JB; ++j) { xc_h[j] = xn_h[j]; if constexpr (NPL == 2) xc_l[j] = xn_l[j]; }
     wc_h = wn_h;
@@ -344,30 +325,17 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
         for (int j = 0; j < JB; ++j) { xc_h[j] = xn_h[j]; if constexpr (NPL == 2) xc_l[j] = xn_l[j]; }
       }
     }
-    ZK_FINE(1)
     advance_load();
     if (++c_k == nk) { c_k = 0; epi_pending = true; }
     // ---- step c_step+1 must have landed; NST-2 younger steps may stay in flight.  xc/wc now hold the fragments of
     //      the deferred chunk NCH-1 (read from this slot BEFORE the barrier that frees it) ----
-    if (!(a.ablate & 2)) {
-      if (l_step - c_step - 2 >= NST - 2) wait_vmcnt<INFLIGHT>();
-      else wait_vmcnt<0>();
-    }
-    ZK_FINE(2)
+    if (l_step - c_step - 2 >= NST - 2) wait_vmcnt<INFLIGHT>();
+    else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    ZK_FINE(3)
-    if (!(a.ablate & 4)) __builtin_amdgcn_s_barrier();
-    ZK_FINE(4)
-  }
-  if (fine) {
-    long long* o = st + (wave == 0 ? 6 : 11);
-    for (int q = 0; q < 5; ++q) o[q] = fs[q];
+    __builtin_amdgcn_s_barrier();
   }
   mfma_chunk(NCH - 1, 0, 0);
-  if (stamp && c_ord < 2) st[2 + 2 * c_ord] = (long long)__builtin_amdgcn_s_memtime();
   epilogue();
-  if (stamp && c_ord <= 2) st[1 + 2 * c_ord] = (long long)__builtin_amdgcn_s_memtime();
-  if (stamp) { st[13] = (long long)__builtin_amdgcn_s_memtime(); st[15] = (long long)__builtin_amdgcn_s_memrealtime(); }
 }
 
 template <int NSPLIT, int EPI>

@@ -1,3 +1,5 @@
+// FROZEN copy of the round-1 ZK_F16C8 GEMM kernel (probe library only): the baseline that tools/gemm_ab.py times
+// variants of gemm_c8.hip against.
 // MFMA GEMM, "fp16 + fp8-corrected" mode (ZK_F16C8):  out[M,N] = X[M,K] · W[N,K]^T + bias  (+ fused epilogue)
 //
 // Same role as gemm.hip (every nn.Linear of ASTAttention / ASTMLP and the patch-embedding Conv2d-as-GEMM,
@@ -58,7 +60,7 @@ typedef int i8v_t __attribute__((ext_vector_type(8)));
 struct frag_t { i4v_t a, b; };
 
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
+__global__ __launch_bounds__(512) void gemm_c8v1_kernel(const zk_gemm_args a) {
   constexpr int BM = 256, BN = 256, BK = 64, WM = 2, WN = 4;
   constexpr int ROWB = 128, CPR = 8, RPI = 8;
   constexpr int TM = BM / WM, TN = BN / WN;       // 128 x 64 per wave
@@ -400,9 +402,9 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 }
 
 template <int EPI>
-void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
+void launch_cfg_v1(const zk_gemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144;
-  auto k = gemm_c8_kernel<EPI>;
+  auto k = gemm_c8v1_kernel<EPI>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   const int ntiles = ((a.M + 255) / 256) * (a.N / 256);
@@ -413,11 +415,11 @@ void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
 }  // namespace
 
 // Host-side shape contract as zk_launch_gemm: N % 256 == 0, K % 64 == 0, M >= 1; x_lo / w_lo are c8 planes.
-void zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s) {
+void zk_launch_gemm_c8_v1(const zk_gemm_args& a, int epi, hipStream_t s) {
   switch (epi) {
-    case ZK_EPI_STORE: launch_cfg<ZK_EPI_STORE>(a, s); break;
-    case ZK_EPI_GELU: launch_cfg<ZK_EPI_GELU>(a, s); break;
-    case ZK_EPI_RESID: launch_cfg<ZK_EPI_RESID>(a, s); break;
-    default: launch_cfg<ZK_EPI_PATCH>(a, s); break;
+    case ZK_EPI_STORE: launch_cfg_v1<ZK_EPI_STORE>(a, s); break;
+    case ZK_EPI_GELU: launch_cfg_v1<ZK_EPI_GELU>(a, s); break;
+    case ZK_EPI_RESID: launch_cfg_v1<ZK_EPI_RESID>(a, s); break;
+    default: launch_cfg_v1<ZK_EPI_PATCH>(a, s); break;
   }
 }

@@ -86,8 +86,6 @@ struct zk_gemm_args {
   const float* pos;    // PATCH: position embeddings [1214, 768]
   int lo_n_limit;      // STORE: write the lo plane only for n < lo_n_limit
   int w_exp;           // ZK_F16C8: the weight's c8 plane holds (fp8(W·2^w_exp), fp8((W-Wh)·2^(w_exp+11)))
-  long long* stamps;   // diagnostic only (ZK_GEMM_STAMPS): [grid][16] s_memtime stamps, nullptr in production
-  int ablate;          // diagnostic only (ZK_GEMM_ABLATE): timing-only knobs, 0 in production
 };
 
 // launchers (each file owns its kernels)

@@ -348,7 +348,7 @@ void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias,
   a.x_hi = x.hi; a.x_lo = x.lo; a.w_hi = w.hi; a.w_lo = (nsplit == ZK_F16C8) ? w.c8 : w.lo; a.bias = bias;
   a.M = M; a.N = N; a.K = K;
   a.o_hi = out.hi; a.o_lo = (nsplit != ZK_F16) ? out.lo : nullptr;
-  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.w_exp = w.exp; a.stamps = nullptr; a.ablate = 0;
+  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.w_exp = w.exp;
   if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
   else zk_launch_gemm(a, epi, nsplit, c->stream);
 }
@@ -571,7 +571,8 @@ int zk_set_async(zk_ctx* c, int e) { if (!c) return ZK_E_ARG; c->async = e != 0;
 int zk_synchronize(zk_ctx* c) { if (!c) return ZK_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return ZK_OK; }
 int zk_set_micro_batch(zk_ctx* c, int32_t w) {
   if (!c) return ZK_E_ARG;
-  if (w < 0 || w > 4096) return fail(c, ZK_E_ARG, "micro batch %d out of range [0,4096] (0 = auto)", w);
+  // 512 windows (M = 621,568 token rows, ~21 GB of activation planes) is the largest micro-batch the test suite runs
+  if (w < 0 || w > 512) return fail(c, ZK_E_ARG, "micro batch %d out of range [0,512] (0 = auto)", w);
   c->micro_batch = w;
   return ZK_OK;
 }
@@ -974,7 +975,8 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   const size_t no = orows * N;
   float *dx, *dw, *dbias, *dres = nullptr, *dpos = nullptr; half_t *xh, *xl, *wh, *wl, *oh = nullptr, *ol = nullptr;
   HIPCHK(c, hipMalloc((void**)&dx, nx * 4)); HIPCHK(c, hipMalloc((void**)&dw, nw * 4)); HIPCHK(c, hipMalloc((void**)&dbias, (size_t)N * 4));
-  // x planes are padded to whole 256-row tiles (the ZK_F16C8 kernel stages the M tail unclamped; see gemm_c8.hip)
+  // x planes are padded by one 256-row tile (the kernels clamp their M-tail rows to M-1; the pad only keeps a mistake
+  // in that clamp from faulting)
   const size_t nxp = nx + (size_t)256 * K;
   HIPCHK(c, hipMalloc((void**)&xh, nxp * 2)); HIPCHK(c, hipMalloc((void**)&xl, nxp * 2));
   HIPCHK(c, hipMemset(xh, 0, nxp * 2)); HIPCHK(c, hipMemset(xl, 0, nxp * 2));
@@ -1001,64 +1003,10 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   a.x_hi = xh; a.x_lo = nsplit != ZK_F16 ? xl : nullptr; a.w_hi = wh; a.w_lo = nsplit != ZK_F16 ? wl : nullptr; a.bias = dbias;
   a.M = M; a.N = N; a.K = K; a.o_hi = oh; a.o_lo = nsplit != ZK_F16 ? ol : nullptr; a.resid = dres; a.pos = dpos; a.lo_n_limit = N;
   a.w_exp = w_exp;
-  a.stamps = nullptr;
-  a.ablate = getenv("ZK_GEMM_ABLATE") ? atoi(getenv("ZK_GEMM_ABLATE")) : 0;
-  long long* dstamps = nullptr;
-  if (getenv("ZK_GEMM_STAMPS")) {
-    HIPCHK(c, hipMalloc((void**)&dstamps, 256 * 16 * 8));
-    HIPCHK(c, hipMemset(dstamps, 0, 256 * 16 * 8));
-    a.stamps = dstamps;
-  }
   if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
   else zk_launch_gemm(a, epi, nsplit, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (dstamps && nsplit == ZK_F16C8) {
-    std::vector<long long> st(256 * 16);
-    HIPCHK(c, hipMemcpy(st.data(), dstamps, st.size() * 8, hipMemcpyDeviceToHost));
-    double cyc = 0, clk = 0; int nb = 0;
-    for (int b = 0; b < 256; ++b) {
-      const long long* s = &st[(size_t)b * 16];
-      if (!s[0] || !s[13] || s[15] <= s[14]) continue;
-      cyc += (double)(s[13] - s[1]); clk += (double)(s[13] - s[0]) / (double)(s[15] - s[14]) * 100.0; ++nb;
-    }
-    const int tiles = ((M + 255) / 256) * (N / 256);
-    const double steps = (double)((tiles + 255) / 256) * (K / 64) * 2;
-    if (nb) fprintf(stderr, "[stamps c8] M=%d N=%d K=%d epi=%d blocks=%d: %.0f ticks per ring step (incl. epilogues), shader clock %.0f MHz\n",
-                    M, N, K, epi, nb, cyc / nb / steps, clk / nb);
-    {   // ZK_C8_TIMING builds only (zeros otherwise)
-      double f[6] = {0}; int nf = 0;
-      for (int b = 0; b < 256; ++b) { const long long* s = &st[(size_t)b * 16]; if (!s[6]) continue; for (int q = 0; q < 6; ++q) f[q] += (double)s[6 + q]; ++nf; }
-      if (nf) fprintf(stderr, "[timing c8] per ring step: wave0 work %.0f land %.0f barrier %.0f | wave4 work %.0f land %.0f barrier %.0f\n",
-                      f[0]/nf/steps, f[1]/nf/steps, f[2]/nf/steps, f[3]/nf/steps, f[4]/nf/steps, f[5]/nf/steps);
-    }
-    (void)hipFree(dstamps); dstamps = nullptr;
-  }
-  if (dstamps) {
-    std::vector<long long> st(256 * 16);
-    HIPCHK(c, hipMemcpy(st.data(), dstamps, st.size() * 8, hipMemcpyDeviceToHost));
-    double pro = 0, loop0 = 0, epi0 = 0, loop1 = 0, epi1 = 0; int nb = 0, nb1 = 0;
-    for (int b = 0; b < 256; ++b) {
-      const long long* s = &st[(size_t)b * 16];
-      if (!s[0] || !s[2]) continue;
-      pro += (double)(s[1] - s[0]); loop0 += (double)(s[2] - s[1]); epi0 += (double)(s[3] - s[2]); ++nb;
-      if (s[4]) { loop1 += (double)(s[4] - s[3]); epi1 += (double)(s[5] - s[4]); ++nb1; }
-    }
-    {
-      double clk = 0; int nc = 0;
-      for (int b = 0; b < 256; ++b) { const long long* s = &st[(size_t)b * 16]; if (s[0] && s[13] && s[15] > s[14]) { clk += (double)(s[13] - s[0]) / (double)(s[15] - s[14]) * 100.0; ++nc; } }
-      if (nc) fprintf(stderr, "[clock] in-kernel shader clock %.0f MHz (s_memtime / s_memrealtime, %d blocks)\n", clk / nc, nc);
-    }
-    if (nb) fprintf(stderr, "[stamps] M=%d N=%d K=%d ns=%d epi=%d blocks=%d: prologue %.0f  loop0 %.0f  epi0 %.0f | loop1 %.0f epi1 %.0f (s_memtime ticks, nb1=%d)\n",
-                    M, N, K, nsplit, epi, nb, pro / nb, loop0 / nb, epi0 / nb, nb1 ? loop1 / nb1 : 0.0, nb1 ? epi1 / nb1 : 0.0, nb1);
-    if (a.ablate & 8) {
-      double f[10] = {0}; int nf = 0;
-      for (int b = 0; b < 256; ++b) { const long long* s = &st[(size_t)b * 16]; if (!s[0] || !s[6]) continue; for (int q = 0; q < 10; ++q) f[q] += (double)s[6 + q]; ++nf; }
-      if (nf) fprintf(stderr, "[fine] per-block totals / steps: wave0 slot0 %.0f chunks %.0f vmcnt %.0f lgkm %.0f barrier %.0f | wave4 slot0 %.0f chunks %.0f vmcnt %.0f lgkm %.0f barrier %.0f (steps=%d)\n",
-                      f[0]/nf/(K/32), f[1]/nf/(K/32), f[2]/nf/(K/32), f[3]/nf/(K/32), f[4]/nf/(K/32), f[5]/nf/(K/32), f[6]/nf/(K/32), f[7]/nf/(K/32), f[8]/nf/(K/32), f[9]/nf/(K/32), K/32);
-    }
-    (void)hipFree(dstamps);
-  }
   if (dres) HIPCHK(c, hipMemcpy(out, dres, no * 4, hipMemcpyDeviceToHost));
   else {
     std::vector<uint16_t> h(no), l(no);

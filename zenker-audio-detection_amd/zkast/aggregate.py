@@ -86,3 +86,58 @@ def aggregate(outputs_dir: str, threshold: float = 0.5):
                     "balanced_accuracy": balanced},
     }
     return summary, rows
+
+
+ROW_FIELDS = ["patient_id", "gt", "ratio", "predicted_label", "tp", "tn", "fp", "fn", "swallow_windows",
+              "zenker_windows", "healthy_windows", "total_windows", "json_path"]
+
+
+def write_outputs(summary: dict, rows: List[dict], csv_path: Optional[str] = None, json_path: Optional[str] = None) -> None:
+    """The two optional artefacts of utils/aggregate_2stage_results.py:196-237: a per-patient CSV (header =
+    ROW_FIELDS, one row per patient JSON) and a {"summary", "patients"} JSON."""
+    import csv
+    if csv_path:
+        with open(csv_path, "w", newline="") as cf:
+            w = csv.DictWriter(cf, fieldnames=ROW_FIELDS)
+            w.writeheader()
+            for r in rows:
+                w.writerow({k: r.get(k) for k in ROW_FIELDS})
+    if json_path:
+        with open(json_path, "w") as jf:
+            json.dump({"summary": summary, "patients": [{k: r.get(k) for k in ROW_FIELDS} for r in rows]}, jf, indent=2)
+
+
+def build_arg_parser():
+    """Same flags as utils/aggregate_2stage_results.py:240-266."""
+    import argparse
+    ap = argparse.ArgumentParser(description="Aggregate two-stage per-patient inference JSON outputs.")
+    ap.add_argument("--outputs-dir", default="outputs", help="Directory containing *_2stage.json files.")
+    ap.add_argument("--threshold", type=float, default=0.5, help="Zenker ratio threshold for positive prediction.")
+    ap.add_argument("--csv", help="Optional CSV path for per-patient rows.")
+    ap.add_argument("--json", help="Optional JSON path for full summary + per-patient data.")
+    ap.add_argument("--verbose", action="store_true", help="Verbose logging.")
+    ap.add_argument("--store-output", action="store_true",
+                    help="Store json and csv with default name in output folder.")
+    return ap
+
+
+def main(argv=None):
+    """`python -m zkast.aggregate --outputs-dir <dir> [--threshold t] [--csv p] [--json p] [--store-output]`:
+    prints the summary as JSON (:194); --store-output writes per_patient_results.csv and aggregate_summary.json
+    into the outputs directory (:197-199), --csv / --json name the files explicitly and win over the defaults."""
+    args = build_arg_parser().parse_args(argv)
+    summary, rows = aggregate(args.outputs_dir, args.threshold)
+    print(json.dumps(summary, indent=2))
+    csv_path = args.csv or (os.path.join(args.outputs_dir, "per_patient_results.csv") if args.store_output else None)
+    json_path = args.json or (os.path.join(args.outputs_dir, "aggregate_summary.json") if args.store_output else None)
+    write_outputs(summary, rows, csv_path, json_path)
+    if args.verbose:
+        if csv_path:
+            print(f"[INFO] Wrote per-patient CSV: {csv_path}")
+        if json_path:
+            print(f"[INFO] Wrote aggregate JSON: {json_path}")
+    return summary
+
+
+if __name__ == "__main__":  # pragma: no cover
+    main()
