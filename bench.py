@@ -7,17 +7,26 @@
         bench.py --gpus N --steps K --warmup W
 
 Workload (config.workload): BASELINE.json configs[2] — batch of 1024 synthetic 1 s / 0.5 s-hop windows per GPU, cut on
-the device from one resident 16 kHz recording; gate rate g = 1.0 (every window goes through BOTH stages: "AST x2",
-the worst case of SURVEY.md §8d).  A step = log-mel of the 1024 windows + stage-1 forward + gate selection +
-stage-2 forward on the selected windows (+ the RCCL all-gather of both logit tables when N > 1).
-Weights are the synthetic "wide" set (no checkpoint exists offline); data and weights are stated in the JSON line.
-The headline `value` is measured in a compute mode that meets the 1e-3 logit tolerance: f16c8 (fp16 MFMA pass + one fp8
-pass carrying the split corrections; ~1.5e-4 measured).  The 3-pass f16x3 mode (same tolerance) and the single-pass
-fp16 rate (fails the tolerance) are reported beside it with their measured logit differences, never as `value`.
+the device from one resident 16 kHz recording.  A step = ONE call of the product's cascade entry point `zk_two_stage`
+(log-mel of the 1024 windows, stage-1 forward, on-device gate + compaction, the host sync that sizes stage 2, stage-2
+forward on the gated windows) with device-resident inputs and outputs, plus — when N > 1 — the RCCL all-gather of both
+logit tables through the C ABI (`zk_allgather_logits`; torch.distributed only ships the 128-byte RCCL id at start-up).
+
+Gate rate g (SURVEY.md §8d knob): random weights give arbitrary gating, so the stage-1 classifier bias is shifted until
+every window's argmax is "swallow" (calibration pass before the timed region) and the fraction g that goes on to stage 2
+is then set with the cascade's own threshold `thr1` (the (1-g) quantile of p_swallow).  Headline `value`: g = 1.0 (every
+window runs BOTH stages, the worst case "AST x2"); g = 0.5 and 0.1 are reported beside it in `gate_sweep`.
+
+Weights are the synthetic "wide" set (no checkpoint exists offline); data and weights are stated in the JSON line.  The
+headline is measured in a compute mode that meets the 1e-3 logit tolerance: f16c8 (fp16 MFMA pass + one fp8 pass carrying
+the split corrections; ~1.5e-4 measured).  The 3-pass f16x3 mode (same tolerance) and the single-pass fp16 rate (fails
+the tolerance) are reported beside it with their measured logit differences, never as `value`.
 """
 import argparse
+import hashlib
 import json
 import os
+import struct
 import sys
 import time
 
@@ -29,8 +38,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_WINDOW_STAGE = 261.03e9          # dense AST forward at S=1214
 PEAK_F16_DENSE = 2.5e15                   # MI355X_MICROARCH.md: BF16/FP16 MFMA dense peak
-S, D, F = 1214, 768, 3072
-GEMM_SHAPES = {"gemm_qkv": (3 * D, D), "gemm_o": (D, D), "gemm_fc1": (F, D), "gemm_fc2": (D, F)}
+TRAFFIC_FILE = "r02_pmc_traffic.json"     # rocprofv3 --pmc passes of this round (tools/pmc_traffic.py)
 
 
 def main():
@@ -39,16 +47,18 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step")
-    ap.add_argument("--gate-rate", type=float, default=1.0, help="fraction of windows forced through stage 2")
+    ap.add_argument("--gate-rate", type=float, default=1.0, help="fraction of windows that go on to stage 2 (headline)")
     ap.add_argument("--micro-batch", type=int, default=0, help="0 = library default (auto)")
     ap.add_argument("--mode", default="f16c8", choices=["f16c8", "f16x3", "f16"])
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary f16x3 / single-pass fp16 measurements")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the g = 0.5 / 0.1 gate-rate lines")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-windows", type=int, default=6)
+    ap.add_argument("--cpu-windows", type=int, default=4,
+                    help="CPU-baseline sample (default keeps the leg at ~20-30 s; SURVEY §8d's N=64 x 3: --cpu-windows 64 --cpu-repeats 3)")
+    ap.add_argument("--cpu-repeats", type=int, default=1)
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -59,51 +69,76 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from zkast import ZkASTConfig, ZkASTFeatureExtractor, ZkASTForAudioClassification, lib, synth
+    from zkast import ZkASTConfig, ZkASTForAudioClassification, lib, synth
+    from zkast import dist as zdist
 
     ctx = lib.get_context(local_rank)
     ctx.set_micro_batch(args.micro_batch)
+    if world > 1:      # host channel for the RCCL unique id; every collective of the bench then runs through the C ABI
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group("gloo", rank=rank, world_size=world)
+        zdist.init_comm(ctx, rank, world)
+
     S1 = (-1.1509622, 3.5340312)
     S2 = (-6.5, 2.75)
     sd1 = synth.make_ast_weights(21, "wide")
     sd2 = synth.make_ast_weights(22, "wide")
-    m1 = ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd1, stage=0, compute_mode=args.mode,
-                                     device=local_rank, fx_mean=S1[0], fx_std=S1[1])
-    m2 = ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd2, stage=1, compute_mode=args.mode,
-                                     device=local_rank, fx_mean=S2[0], fx_std=S2[1])
     B = args.batch
     hop, win = 8000, 16000
     n_samples = win + (B - 1) * hop
     rec = synth.synth_recording(100 + rank, n_samples)
     audio = torch.from_numpy(rec).to(dev)                       # inputs resident in HBM before the timed region
     s1_logits = torch.empty((B, 2), dtype=torch.float32, device=dev)
-    s2_logits = torch.empty((B, 2), dtype=torch.float32, device=dev)
-    K = max(1, int(round(args.gate_rate * B)))
+    s2_logits = torch.zeros((B, 2), dtype=torch.float32, device=dev)
+    sw_idx = torch.empty((B,), dtype=torch.int32, device=dev)
+    sw_cnt = torch.zeros((4,), dtype=torch.int32, device=dev)
     if world > 1:
-        g1 = torch.empty((world * B, 2), dtype=torch.float32, device=dev)
-        g2 = torch.empty((world * B, 2), dtype=torch.float32, device=dev)
+        g1 = torch.empty((world, B, 2), dtype=torch.float32, device=dev)
+        g2 = torch.empty((world, B, 2), dtype=torch.float32, device=dev)
+
+    # ---- calibration (untimed): shift the stage-1 "swallow" bias so that every window passes the argmax test ----
+    m1 = ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd1, stage=0, compute_mode=args.mode,
+                                     device=local_rank, fx_mean=S1[0], fx_std=S1[1])
+    ctx.logmel(audio, n_samples, 0, hop, win, B)
+    ctx.ast_forward(0, None, None, B, s1_logits)
+    l = s1_logits.cpu().numpy()
+    shift = float(-(l[:, 1] - l[:, 0]).min() + 0.05)
+    sd1s = dict(sd1)
+    sd1s["classifier.dense.bias"] = sd1["classifier.dense.bias"].copy()
+    sd1s["classifier.dense.bias"][1] += np.float32(shift)
+    m1 = ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd1s, stage=0, compute_mode=args.mode,
+                                     device=local_rank, fx_mean=S1[0], fx_std=S1[1])
+    m2 = ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd2, stage=1, compute_mode=args.mode,
+                                     device=local_rank, fx_mean=S2[0], fx_std=S2[1])
+    ctx.ast_forward(0, None, None, B, s1_logits)
+    p_sw = torch.softmax(s1_logits, dim=1)[:, 1].cpu().numpy().astype(np.float32)
+    assert (p_sw > 0.5).all()
+
+    def thr_for(g):      # the cascade's own gate threshold that lets the top-g fraction through
+        k = max(1, int(round(g * B)))
+        srt = np.sort(p_sw)[::-1]
+        return 0.5 if k >= B else float(np.float32(0.5) * (srt[k - 1] + srt[k])), k
+
+    state = {"thr": thr_for(args.gate_rate)[0]}
 
     def step():
-        ctx.logmel(audio, n_samples, 0, hop, win, B)
-        ctx.ast_forward(0, None, None, B, s1_logits)
-        # gate selection: the top-g fraction of stage-1 p_swallow, ascending window order (SURVEY.md §8d knob)
-        p_sw = torch.softmax(s1_logits, dim=1)[:, 1]
-        idx = torch.sort(torch.topk(p_sw, K).indices).values.to(torch.int32).contiguous()
-        torch.cuda.current_stream().synchronize()
-        ctx.ast_forward(1, None, idx, K, s2_logits)
+        ctx.two_stage_into(audio, n_samples, 0, hop, win, B, state["thr"], None, s1_logits, sw_idx, sw_cnt, s2_logits)
         if world > 1:
-            dist.all_gather_into_tensor(g1, s1_logits)
-            dist.all_gather_into_tensor(g2, s2_logits)
+            ctx.allgather_logits(s1_logits, B, 2, g1)
+            ctx.allgather_logits(s2_logits, B, 2, g2)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
+        if world > 1:
+            ctx.allgather_bytes(b"\0")
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        return max(struct.unpack("<d", b)[0] for b in ctx.allgather_bytes(struct.pack("<d", x)))
 
     def timed(steps, warmup, profile=False):
         for _ in range(warmup):
@@ -117,17 +152,15 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         prof = ctx.prof_end() if profile else None
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, prof
+        return max_over_ranks(dt), prof
 
     dt, prof = timed(args.steps, args.warmup, profile=True)
+    K = int(sw_cnt.cpu().numpy()[0])
     windows = world * B * args.steps
     value = windows / dt
 
-    # ---- per-kernel roofline from the HIP-event timings of the timed region (rank 0) ----
+    # ---- per-kernel roofline from the HIP-event timings of the timed region (rank 0; events are recorded by the
+    #      library on the context's own stream, the stream its kernels are launched on) ----
     roof_all = {}
     for name in ("gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention"):
         ms, cnt, fl = prof[name]                               # fl = algorithmic FLOPs EXECUTED (exact pruning applied)
@@ -143,16 +176,20 @@ def main():
     roofline = {"kernel": dom, "bound": "mfma", "achieved": roof_all[dom]["tflops"], "peak": PEAK_F16_DENSE / 1e12,
                 "unit": "TFLOP/s", "frac": roof_all[dom]["tflops"] * 1e12 / PEAK_F16_DENSE, "traffic": None,
                 "ms_per_launch": roof_all[dom]["ms_per_launch"], "launches": roof_all[dom]["launches"]}
-    # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; the value is the one
-    # measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH correction applied) and
-    # committed under profiles/ (same kernel, micro-batch 107)
+    # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; the value is the one measured
+    # with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH correction applied) and committed
+    # under profiles/ TOGETHER WITH the sha256 of the libzkast.so it was measured on: a file measured on another build
+    # is refused (traffic stays null) instead of silently going stale.
     try:
-        tr_file = "r01_f_pmc_traffic.json" if args.mode == "f16c8" else "r01_b_pmc_traffic.json"
-        tr = json.load(open(os.path.join(ROOT, "profiles", tr_file)))["kernels"]
-        key = {"gemm_fc1": "gemm_fc1(gelu)", "gemm_qkv": "gemm_qkv(store)", "gemm_fc2": "gemm_resid(o,fc2)",
-               "gemm_o": "gemm_resid(o,fc2)", "attention": "attention"}[dom]
-        roofline["traffic"] = tr[key]["hbm_bytes_per_launch_corrected"]
-        roofline["traffic_source"] = f"profiles/{tr_file} (rocprofv3 --pmc, separate passes)"
+        tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+        so_hash = hashlib.sha256(open(lib.LIB_PATH, "rb").read()).hexdigest()
+        key = {"gemm_fc1": "gemm_fc1(gelu)", "gemm_qkv": "gemm_qkv(store)", "gemm_fc2": "gemm_fc2(resid)",
+               "gemm_o": "gemm_o(resid)", "attention": "attention"}[dom]
+        if tr.get("libzkast_sha256") == so_hash and args.mode == "f16c8":
+            roofline["traffic"] = tr["kernels"][key]["hbm_bytes_per_launch_corrected"]
+            roofline["traffic_source"] = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc, separate passes, same libzkast.so)"
+        else:
+            roofline["traffic_source"] = f"profiles/{TRAFFIC_FILE} was measured on another build of libzkast.so: not used"
     except Exception:
         pass
     e2e_flops = value / world * (1.0 + K / B) * FLOP_PER_WINDOW_STAGE
@@ -160,10 +197,12 @@ def main():
         "metric": "1-s audio windows/sec two-stage (mel+ASTx2)", "value": value, "unit": "windows/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
-        "config": {"workload": "configs[2]: full two-stage cascade, batch=1024 1-s windows per GPU, hop 0.5 s, "
-                               f"gate rate g={K / B:.2f}", "windows_per_gpu": B, "stage2_windows_per_gpu": K,
-                   "micro_batch": args.micro_batch, "weights": "synthetic splitmix64 'wide' set (seeds 21/22)",
-                   "parallelism": f"window-sharded x{world}, RCCL all-gather of logits" if world > 1 else "single GPU"},
+        "config": {"workload": "configs[2]: full two-stage cascade (zk_two_stage), batch=1024 1-s windows per GPU, hop "
+                               f"0.5 s, gate rate g={K / B:.2f}", "windows_per_gpu": B, "stage2_windows_per_gpu": K,
+                   "micro_batch": args.micro_batch, "weights": "synthetic splitmix64 'wide' set (seeds 21/22), stage-1 "
+                   f"swallow bias shifted by {shift:+.3f} so that thr1 alone sets the gate rate",
+                   "parallelism": f"window-sharded x{world}, RCCL all-gather of both logit tables through the C ABI"
+                                  if world > 1 else "single GPU"},
         "roofline": roofline,
         "roofline_end_to_end": {"algorithmic_gflop_per_window_stage": FLOP_PER_WINDOW_STAGE / 1e9,
                                 "achieved_tflops_per_gpu": e2e_flops / 1e12, "frac_of_f16_dense_peak": e2e_flops / PEAK_F16_DENSE,
@@ -174,9 +213,24 @@ def main():
         "kernels": roof_all,
     }
 
+    # ---- gate-rate sweep (g in {0.1, 0.5, 1.0}); windows/s counts stage-1 windows, as the headline ----
+    if not args.no_sweep:
+        sweep = {f"{K / B:.2f}": {"value": value, "unit": "windows/s", "stage2_windows": K}}
+        nsw = max(1, args.steps // 2)
+        for g in (0.5, 0.1):
+            state["thr"], _k = thr_for(g)
+            dts, _ = timed(nsw, 1)
+            kk = int(sw_cnt.cpu().numpy()[0])
+            sweep[f"{kk / B:.2f}"] = {"value": world * B * nsw / dts, "unit": "windows/s", "stage2_windows": kk,
+                                      "thr1": state["thr"]}
+        state["thr"] = thr_for(args.gate_rate)[0]
+        out["gate_sweep"] = sweep
+
     # ---- secondary: the 3-pass mode (same tolerance) and single-pass fp16 (fails the 1e-3 tolerance), each with its
     #      measured stage-1 logit difference to the headline mode ----
     if not args.no_fast and args.mode == "f16c8":
+        step()
+        barrier()
         ref1 = s1_logits.cpu().numpy().copy()
         nsec = max(1, args.steps // 2)
         for key, mode, note in (("x3_mode", "f16x3", "(hi,lo) fp16 pairs, 3 MFMA passes; also meets the 1e-3 logit tolerance"),
@@ -190,7 +244,7 @@ def main():
         m1.set_compute_mode(args.mode)
         m2.set_compute_mode(args.mode)
 
-    # ---- BASELINE.json configs[1] as an extra line: batch 256, stage-1 only (log-mel + forward), both modes ----
+    # ---- BASELINE.json configs[1] as an extra line: batch 256, stage-1 only (log-mel + forward), all modes ----
     if rank == 0 and world == 1:
         def stage1_b256(reps=3):
             n256 = min(256, B)
@@ -212,37 +266,47 @@ def main():
         from oracle import ast_oracle as orc
         n_cpu = args.cpu_windows
         wins = orc.window_audio(rec[: win + (n_cpu - 1) * hop])
-        W1, W2 = orc.ASTWeights(sd1), orc.ASTWeights(sd2)
+        W1, W2 = orc.ASTWeights(sd1s), orc.ASTWeights(sd2)
         try:                                    # report the BLAS threads actually used, not the box's core count
             from threadpoolctl import threadpool_info
             blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
         except Exception:
             blas_threads = None
         allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-        t0 = time.perf_counter()
-        f1 = orc.extract_features(wins, *S1)
-        l1 = orc.ast_forward(f1, W1)
-        f2 = orc.extract_features(wins, *S2)
-        l2 = orc.ast_forward(f2, W2)
-        tc = time.perf_counter() - t0
-        del f2
+        reps = []
+        for _ in range(max(1, args.cpu_repeats)):
+            t0 = time.perf_counter()
+            f1 = orc.extract_features(wins, *S1)
+            t1 = time.perf_counter()
+            l1 = orc.ast_forward(f1, W1)
+            t2 = time.perf_counter()
+            f2 = orc.extract_features(wins, *S2)
+            t3 = time.perf_counter()
+            orc.ast_forward(f2, W2)
+            t4 = time.perf_counter()
+            reps.append((t4 - t0, (t1 - t0) + (t3 - t2), (t2 - t1) + (t4 - t3)))
+            del f2
+        reps.sort()
+        tc, t_mel, t_fwd = reps[len(reps) // 2]
         out["cpu_baseline"] = {"value": n_cpu / tc, "unit": "windows/s",
                                "cores": blas_threads if blas_threads else allowed, "kind": "port",
-                               "sample": f"{n_cpu} windows x (log-mel + AST) x 2 stages, numpy/BLAS fp32 oracle, "
-                                         f"{tc:.1f} s wall; BLAS threads {blas_threads}, cpus allowed {allowed}, "
-                                         f"os.cpu_count {os.cpu_count()} (log-mel part is single-threaded numpy)"}
-        out["parity_in_bench"] = {"stage1_logit_max_abs_err_vs_oracle": None}
+                               "mel_windows_per_s_per_stage": 2 * n_cpu / t_mel,
+                               "forward_windows_per_s_per_stage": 2 * n_cpu / t_fwd,
+                               "sample": f"{n_cpu} windows x (log-mel + AST) x 2 stages, numpy/BLAS fp32 oracle, median of "
+                                         f"{len(reps)} run(s), {tc:.1f} s wall each (mel {t_mel:.1f} s single-threaded "
+                                         f"numpy, forward {t_fwd:.1f} s on {blas_threads} BLAS threads); cpus allowed "
+                                         f"{allowed}, os.cpu_count {os.cpu_count()}"}
         # re-run the headline mode once so the comparison is against its logits
-        ctx.logmel(audio, n_samples, 0, hop, win, B)
-        ctx.ast_forward(0, None, None, B, s1_logits)
-        out["parity_in_bench"]["stage1_logit_max_abs_err_vs_oracle"] = float(
-            np.abs(s1_logits.cpu().numpy()[:n_cpu] - l1).max())
-        del l2
+        step()
+        barrier()
+        out["parity_in_bench"] = {"stage1_logit_max_abs_err_vs_oracle": float(
+            np.abs(s1_logits.cpu().numpy()[:n_cpu] - l1).max()), "windows": n_cpu}
 
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
-        dist.destroy_process_group()
+        ctx.comm_destroy()
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

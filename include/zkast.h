@@ -83,7 +83,7 @@ int zk_model_set_fx(zk_ctx* ctx, int stage, float fx_mean, float fx_std);
 /* replaces window_audio (:62-75) + ASTFeatureExtractor._extract_fbank_features.  Windows are
  * audio[first_start + i*hop : ... + win], i < n_windows; samples past n_samples read as 0.  The un-normalised
  * log-mel rows stay on the device in the context (the "feature slot"); n_frames = 1 + (win-400)/160, capped at 1024. */
-int zk_logmel(zk_ctx* ctx, const float* audio /*host|device*/, int64_t n_samples, int64_t first_start, int64_t hop,
+int zk_logmel(zk_ctx* ctx, const float* audio /*host|device; NULL = the audio slot*/, int64_t n_samples, int64_t first_start, int64_t hop,
               int32_t win, int32_t n_windows);
 /* replaces ASTFeatureExtractor.__call__(...)["input_values"]: zero-pad the slot to 1024 rows and apply
  * (x - mean) / (2*std) when do_normalize != 0.  out: (n_windows, 1024, 128) fp32, host|device.                     */
@@ -106,12 +106,31 @@ int zk_softmax(zk_ctx* ctx, const float* logits /*host|device*/, int32_t n, int3
  * Gate: argmax == 1 and p_swallow >= thr1 (and p_swallow >= fwd_min_prob when fwd_min_prob >= 0,
  * ..._cache.py:471-478).  Outputs (host|device, caller-sized): s1_logits (N,2), swallow_idx (N), n_swallow (1),
  * s2_logits (N,2) of which the first *n_swallow rows are valid.                                                   */
+/* audio == NULL: run on the audio slot (zk_audio_load); n_samples is then ignored.                                  */
 int zk_two_stage(zk_ctx* ctx, const float* audio, int64_t n_samples, int64_t first_start, int64_t hop, int32_t win,
                  int32_t n_windows, float thr1, float fwd_min_prob, float* s1_logits, int32_t* swallow_idx,
                  int32_t* n_swallow, float* s2_logits);
 /* the gate alone, on device: logits (N,2) -> probs (N,2, may be NULL), ascending indices, count */
 int zk_gate(zk_ctx* ctx, const float* logits, int32_t n, float thr1, float fwd_min_prob, float* probs,
             int32_t* swallow_idx, int32_t* n_swallow);
+
+/* ---- multi-GPU: one process per GPU, windows / patients are sharded by the host code (zkast/dist.py,
+ * zkast/batch.py); the ONLY device exchange is the all-gather of per-window logits after each stage.  The reference is
+ * single-process (src/run_batch_simple_2stage.py:258-292 walks the patient list in one interpreter, the per-patient
+ * script owns one DEVICE, src/test_long_audio_windows_2stage.py:48), so these entry points replace nothing — they are
+ * what lets that loop and forward_probs (:104-113) run on 8 GPUs.  RCCL (librccl.so.1) is dlopen()ed on first use.   */
+/* rank 0: create the 128-byte RCCL unique id; the caller ships it to the other ranks (any host channel)            */
+int zk_comm_unique_id(void* out_128_bytes);
+/* collective over all ranks: bind an RCCL communicator (over xGMI inside a node) to the context.  world == 1 with
+ * unique_id == NULL needs no RCCL and makes every gather below a copy.                                              */
+int zk_comm_init(zk_ctx* ctx, int32_t rank, int32_t world, const void* unique_id_128_bytes);
+int zk_comm_destroy(zk_ctx* ctx);
+int zk_comm_info(zk_ctx* ctx, int32_t* rank, int32_t* world);
+/* all-gather of equally sized logit shards on the context's stream: local (rows_per_rank, cols) fp32 host|device ->
+ * all (world, rows_per_rank, cols) host|device, rank-major.  Ragged shards are padded by the caller (dist.py).       */
+int zk_allgather_logits(zk_ctx* ctx, const float* local, int32_t rows_per_rank, int32_t cols, float* all);
+/* the same for opaque bytes (per-patient summary records of the batch driver, barrier / max-over-ranks of a timing)   */
+int zk_comm_allgather_bytes(zk_ctx* ctx, const void* send, int64_t bytes, void* recv);
 
 /* ---- load_audio (next row) ---------------------------------------------------------------------- */
 /* torchaudio.functional.resample(wav, orig, new) defaults (sinc_interp_hann, width 6, rolloff 0.99);
@@ -125,6 +144,14 @@ int zk_resample(zk_ctx* ctx, const float* in /*host|device*/, int64_t n_in, int3
  * scaling x / 2^(bits-1) (8-bit: (x - 128) / 128).  out holds n_frames floats.                                     */
 int zk_wav_decode(zk_ctx* ctx, const void* data /*host|device*/, int64_t n_bytes, int32_t format_tag, int32_t bits,
                   int32_t channels, float* out /*host|device*/);
+
+/* load_audio as ONE call that stays on the device (src/test_long_audio_windows_2stage.py:53-59): one upload of the
+ * data chunk's bytes, zk_wav_decode, zk_resample to target_sr when sr differs; the mono float32 recording is kept in
+ * the context ("audio slot") for zk_logmel / zk_two_stage(audio = NULL).  n_samples_out may be NULL.                */
+int zk_audio_load(zk_ctx* ctx, const void* data /*host|device*/, int64_t n_bytes, int32_t format_tag, int32_t bits,
+                  int32_t channels, int32_t sr, int32_t target_sr, int64_t* n_samples_out);
+/* length of the audio slot and, when out != NULL, a copy of it (the np.float32 (T,) that load_audio returns)         */
+int zk_audio_get(zk_ctx* ctx, float* out /*host|device*/, int64_t* n_samples);
 
 /* ---- introspection / measurement ---------------------------------------------------------------------------- */
 /* per-kernel-class HIP-event timing over the calls made since zk_prof_begin (on the context's stream).

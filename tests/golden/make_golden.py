@@ -54,9 +54,47 @@ def hf_model(seed, weight_set):
     return m
 
 
+def make_heavy(nrm):
+    """F3b: the "heavy" weight set (heavy-tailed matrices, LayerNorm gain outliers, massive-activation channels) through
+    the real transformers fp32 model: logits, residual-stream checkpoints, and the largest |input| every GEMM kind of
+    the stack sees (what an fp8 value byte with a fixed scale would have to cover)."""
+    feats4 = nrm[[0, 1, 2, 4]]
+    f = {"input_windows": np.array([0, 1, 2, 4]), "tokens": np.array(TOKENS)}
+    m = hf_model(13, "heavy")
+    amax = {"qkv_in": [], "o_in": [], "fc1_in": [], "fc2_in": []}
+    hooks = []
+    for layer in m.audio_spectrogram_transformer.layers:
+        att = layer.attention
+        hooks.append(att.q_proj.register_forward_pre_hook(lambda _m, a: amax["qkv_in"].append(float(a[0].abs().max()))))
+        hooks.append(att.o_proj.register_forward_pre_hook(lambda _m, a: amax["o_in"].append(float(a[0].abs().max()))))
+        hooks.append(layer.mlp.fc1.register_forward_pre_hook(lambda _m, a: amax["fc1_in"].append(float(a[0].abs().max()))))
+        hooks.append(layer.mlp.fc2.register_forward_pre_hook(lambda _m, a: amax["fc2_in"].append(float(a[0].abs().max()))))
+    out = m(torch.from_numpy(feats4), output_hidden_states=True)
+    for h in hooks:
+        h.remove()
+    hs = out.hidden_states
+    seq = m.audio_spectrogram_transformer.layernorm(hs[-1])
+    f["heavy_logits"] = out.logits.numpy()
+    for nm, t in [("emb", hs[0]), ("layer0", hs[1]), ("layer5", hs[6]), ("layer11", hs[12]), ("final_ln", seq)]:
+        f[f"heavy_{nm}_tok"] = t[:, TOKENS].numpy()
+        f[f"heavy_{nm}_norm"] = t.norm(dim=-1).numpy()
+    f["heavy_resid_absmax"] = np.array([float(h.abs().max()) for h in hs])
+    for k, v in amax.items():
+        f[f"heavy_{k}_absmax"] = np.array(v)
+    print("heavy logits", out.logits.numpy().tolist())
+    print("heavy |x| max per GEMM input kind:", {k: round(max(v), 2) for k, v in amax.items()},
+          "residual stream:", round(float(f["heavy_resid_absmax"].max()), 1))
+    np.savez_compressed(os.path.join(HERE, "model_heavy.npz"), **f)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
+    if "--heavy-only" in sys.argv:      # adds model_heavy.npz without touching the other fixtures
+        fx = ASTFeatureExtractor(mean=S1_MEAN, std=S1_STD)
+        nrm = fx(list(synth.golden_windows()), sampling_rate=16000, return_tensors="np")["input_values"]
+        make_heavy(nrm)
+        return
     ref = load_ref("test_long_audio_windows_2stage")
     refc = load_ref("test_long_audio_windows_2stage_cache")
 
@@ -116,6 +154,7 @@ def main():
         print(tag, "logits", out.logits.numpy().tolist())
     f3["tokens"] = np.array(TOKENS)
     np.savez_compressed(os.path.join(HERE, "model.npz"), **f3)
+    make_heavy(nrm)
 
     # ---------------- F4: cascade ----------------
     w16 = synth.synth_windows(seed=3, n_windows=16)

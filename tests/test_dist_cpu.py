@@ -76,3 +76,69 @@ def test_ragged_and_empty_cases():
         ref1, refi, ref2 = zdist.sharded_cascade(n, _fake_logits, 0, 1, thr, None)
         for rank, s1, idx, s2, _ in _run(n, thr):
             assert np.array_equal(s1, ref1) and np.array_equal(idx, refi) and s2.shape == ref2.shape
+
+
+# ---- patient-level sharding of the batch driver (config 5: run_batch_simple_2stage.py equivalent on N ranks) ----
+def _batch_worker(rank, world, port, root, out_dir, patients, q):
+    import json
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zkast import batch, pipeline as pl
+
+    def gather_bytes(b):                       # stand-in for Context.allgather_bytes (RCCL) on the CPU
+        box = [None] * world
+        dist.all_gather_object(box, b)
+        return box
+
+    def fake_run_patient(files, *_a):          # the per-patient cascade itself is covered by the GPU suite
+        n = sum(os.path.getsize(f) for f in files)
+        return {"aggregate": {"files_used": files, "total_windows": n, "overall_zenker_ratio_over_swallow": (n % 7) / 7.0}}
+
+    pl_run, pl.run_patient = pl.run_patient, fake_run_patient
+    try:
+        summ = {}
+        st = batch.run_batch(patients, root, None, None, None, None, out_dir, rank=rank, world=world,
+                             gather_bytes=gather_bytes, summaries=summ, log=lambda *_: None)
+    finally:
+        pl.run_patient = pl_run
+    q.put((rank, st, summ))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_patient_sharded_batch_two_ranks(tmp_path):
+    import json
+    from zkast import batch, pipeline as pl
+    patients = [f"{i:03d}" for i in range(7)] + ["missing"]
+    for i, pid in enumerate(patients[:-1]):
+        d = tmp_path / "Long" / ("Zenker" if i % 2 else "Healthy") / pid
+        d.mkdir(parents=True)
+        for k in range(2):
+            pl.write_wav_pcm16(str(d / f"r{k}.wav"), np.zeros(100 + 10 * i + k, np.float32), 16000)
+    assert batch.shard_patients(patients, 0, 2) == patients[0::2] and batch.shard_patients(patients, 1, 2) == patients[1::2]
+    out = tmp_path / "out"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, str(tmp_path), str(out), patients, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    exp_status = {pid: "ok" for pid in patients[:-1]}
+    exp_status["missing"] = "error"
+    for rank, st, summ in res:                 # every rank ends with the full table, in list order
+        assert st == exp_status and list(st) == patients
+        assert set(summ) == set(patients[:-1])
+    # every patient JSON was written exactly once, by the rank that owns the patient
+    files = sorted(os.listdir(out))
+    assert files == sorted(f"{pid}_2stage.json" for pid in patients[:-1])
+    # the gathered aggregate blocks are what the patient-level aggregation reads from the files
+    from zkast import aggregate as agg
+    summary, rows = agg.aggregate(str(out), 0.5)
+    assert summary["num_patient_results"] == 7
+    assert {r["patient_id"]: r["ratio"] for r in rows} == {pid: res[0][2][pid]["overall_zenker_ratio_over_swallow"] for pid in patients[:-1]}

@@ -60,3 +60,90 @@ def test_two_rank_sharded_cascade_matches_single_process():
     for rank, s1, idx, s2 in res:
         # per-window arithmetic does not depend on which windows share a micro-batch -> bit-identical
         assert np.array_equal(s1, ref1) and np.array_equal(idx, refi) and np.array_equal(s2, ref2)
+
+
+def test_rccl_allgather_through_the_c_abi_world_of_one():
+    """zk_comm_unique_id / zk_comm_init / zk_allgather_logits / zk_comm_allgather_bytes with a REAL RCCL communicator
+    (one rank: all this box has): dlopen of librccl, communicator creation, device and host buffers, ragged byte
+    payloads.  The N > 1 path is the same code with more ranks (bench.py --gpus N, test below)."""
+    import torch
+    from zkast import lib
+    ctx = lib.Context(0)
+    try:
+        ctx.comm_init(0, 1, lib.comm_unique_id())
+        assert ctx.comm_info() == (0, 1)
+        rng = np.random.default_rng(4)
+        x = rng.normal(0, 1, (450, 2)).astype(np.float32)
+        out = np.empty((1, 450, 2), np.float32)
+        ctx.allgather_logits(x, 450, 2, out)                       # host -> host through the staging buffers
+        assert np.array_equal(out[0], x)
+        xd = torch.from_numpy(x).cuda()
+        od = torch.empty((1, 450, 2), dtype=torch.float32, device="cuda")
+        ctx.allgather_logits(xd, 450, 2, od)                       # device -> device on the context's stream
+        assert np.array_equal(od.cpu().numpy()[0], x)
+        assert ctx.allgather_bytes(b"patient 006: ok") == [b"patient 006: ok"] and ctx.allgather_bytes(b"") == [b""]
+        with pytest.raises(lib.ZkError):
+            ctx.comm_init(0, 1, None)                              # a context holds one communicator
+        ctx.comm_destroy()
+        ctx.comm_init(0, 1, None)                                  # world of one without RCCL: gathers are copies
+        ctx.allgather_logits(x, 450, 2, out)
+        assert np.array_equal(out[0], x)
+    finally:
+        ctx.close()
+
+
+def _rccl_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # host channel for the 128-byte unique id only
+    from zkast import dist as zdist
+    from zkast import lib, synth
+    (m1, fx1), (m2, fx2) = _models()
+    try:
+        zdist.init_comm(m1._ctx, rank, world)
+    except lib.ZkError as e:                                          # RCCL refuses two ranks on one device
+        q.put((rank, "refused", str(e), None, None))
+        dist.destroy_process_group()
+        return
+    rec = synth.synth_recording(3, 16000 + 15 * 8000)
+    casc = zdist.ZkShardedCascade(m1, fx1, m2, fx2, rank, world)
+    assert casc.comm_ctx is not None
+    s1, idx, s2 = casc(rec, 1.0, 0.5, 0.5)
+    q.put((rank, "ok", s1, idx, s2, casc.h2d_samples))
+    dist.barrier()
+    m1._ctx.comm_destroy()
+    dist.destroy_process_group()
+
+
+def test_two_rank_rccl_cascade_on_one_gpu():
+    """The RCCL gather with two ranks.  Both ranks sit on the one GPU of the test box; RCCL builds that reject a
+    duplicate device make this a skip (the world-of-one test above still drives the RCCL calls), on the 8-GPU node
+    bench.py runs the same path with one GPU per rank."""
+    from zkast import dist as zdist
+    from zkast import synth
+    (m1, fx1), (m2, fx2) = _models()
+    rec = synth.synth_recording(3, 16000 + 15 * 8000)
+    ref1, refi, ref2 = zdist.ZkShardedCascade(m1, fx1, m2, fx2, 0, 1)(rec, 1.0, 0.5, 0.5)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    try:
+        res = [q.get(timeout=150) for _ in range(2)]
+    except queue.Empty:          # a communicator bootstrap that neither completes nor fails: stop exactly these two
+        for p in procs:
+            p.terminate()
+        pytest.skip("RCCL communicator of two ranks on one device did not come up within 150 s")
+    for p in procs:
+        p.join(120)
+    if any(r[1] == "refused" for r in res):
+        pytest.skip("RCCL refuses two ranks on one device: " + next(r[2] for r in res if r[1] == "refused")[:200])
+    for p in procs:
+        assert p.exitcode == 0
+    for rank, _ok, s1, idx, s2, h2d in res:
+        assert np.array_equal(s1, ref1) and np.array_equal(idx, refi) and np.array_equal(s2, ref2)
+        assert h2d < len(rec) + 16000          # a rank uploads its slices, not the recording per stage

@@ -107,6 +107,36 @@ def test_model_logits_and_checkpoints_vs_golden(G, tag, seed):
     assert err1 <= 2e-2
 
 
+def test_heavy_tailed_weight_set_all_modes(golden_dir):
+    """Trained-like weights ("heavy" synth set: heavy-tailed matrices with log-normal row scales — kurtosis ~18, max|w| ~
+    30 sigma —, LayerNorm gains with 4-8x outlier channels, two massive-activation residual channels of +55 / -40)
+    against the real transformers fp32 run of tests/golden/model_heavy.npz: the parity modes must hold the 1e-3 logit
+    tolerance and the residual-stream checkpoints; the single fp16 pass is reported."""
+    from zkast import lib, synth
+    g = np.load(os.path.join(golden_dir, "model_heavy.npz"))
+    fb = np.load(os.path.join(golden_dir, "fbank.npz"))
+    feats = orc.extract_features(synth.golden_windows()[[0, 1, 2, 4]], float(fb["mean"]), float(fb["std"]))
+    model, _ = _model(13, "heavy", 0)
+    ctx = lib.get_context(0)
+    toks = g["tokens"]
+    assert float(g["heavy_resid_absmax"].max()) > 80.0          # the massive channels are really there
+    errs = {}
+    for mode in ("f16c8", "f16x3", "f16"):
+        model.set_compute_mode(mode)
+        for layer, name in [(0, "layer0"), (5, "layer5"), (11, "layer11")]:
+            ctx.debug_tap(layer)
+            logits = model(feats).logits
+            h = ctx.debug_get_tap(4)
+            if mode != "f16":
+                ref_tok, ref_norm = g[f"heavy_{name}_tok"], g[f"heavy_{name}_norm"]
+                assert np.abs(h[:, toks] - ref_tok).max() <= 2e-4 * np.abs(ref_tok).max(), (mode, name)
+                assert np.abs(np.linalg.norm(h, axis=-1) - ref_norm).max() <= 2e-4 * ref_norm.max(), (mode, name)
+        ctx.debug_tap(-2)
+        errs[mode] = float(np.abs(logits - g["heavy_logits"]).max())
+        print(f"[heavy] {mode} max-abs logit err vs transformers fp32: {errs[mode]:.3e}")
+    assert errs["f16c8"] <= TOL and errs["f16x3"] <= TOL and errs["f16"] <= 5e-2
+
+
 def test_v4_key_scheme_loads_identically(G):
     from zkast import ZkASTConfig, ZkASTForAudioClassification, synth
     sd = synth.make_ast_weights(12, "init")

@@ -32,11 +32,11 @@ done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 objs=()
 for f in $PRODUCT; do [ -f "$OBJ/$f.o" ] && objs+=("$OBJ/$f.o"); done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIBNAME" "${objs[@]}" ${ZK_LINK_LIBS:-}
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIBNAME" "${objs[@]}" -ldl ${ZK_LINK_LIBS:-}
 echo "built $OUT/$LIBNAME"
 if [ "${ZK_PROBES:-0}" = "1" ]; then
   pobjs=("${objs[@]}")
   for f in $PROBES; do [ -f "$OBJ/$f.o" ] && pobjs+=("$OBJ/$f.o"); done
-  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${ZK_PROBES_NAME:-libzkast_probes.so}" "${pobjs[@]}" ${ZK_LINK_LIBS:-}
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${ZK_PROBES_NAME:-libzkast_probes.so}" "${pobjs[@]}" -ldl ${ZK_LINK_LIBS:-}
   echo "built $OUT/${ZK_PROBES_NAME:-libzkast_probes.so}"
 fi

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   constexpr int BIAS_OFF = 2 * STAGE;
   constexpr int SCR_OFF = BIAS_OFF + 2 * 8 * 256;
   constexpr int SCR_STR = 144, SCR_WAVE = 16 * SCR_STR;
+  constexpr int RSC_OFF = SCR_OFF + 8 * SCR_WAVE;      // per wave: 128 row scales (fp32) of its X rows, epilogue only
   constexpr int TILE_B = 16 * ROWB;               // 2048 B between consecutive 16-row tiles
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -216,13 +217,26 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
     f4_t b4[RN];
 #pragma unroll
     for (int i = 0; i < RN; ++i) b4[i] = *(const f4_t*)(bslot + (i * 16 + 4 * fq) * 4);
+    // row-scaled X planes (zk_planes::rowexp): accumulator row m is multiplied by 2^s_m — folded into the bias add as
+    // one fma per element.  The wave's 128 scales go through LDS so that one VGPR at a time holds them.
+    const bool scaled = a.x_rowexp != nullptr;
+    float* rsc = (float*)(smem + RSC_OFF + wave * 512);
+    if (scaled) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        int m = m0 + t * 64 + lane;
+        m = m < a.M ? m : a.M - 1;
+        rsc[t * 64 + lane] = __int_as_float((a.x_rowexp[m] + 127) << 23);
+      }
+    }
+    auto row_scale = [&](int j) __attribute__((always_inline)) { return scaled ? rsc[j * 16 + frow] : 1.0f; };
     if constexpr (EPI == ZK_EPI_PATCH) {
 #pragma unroll
       for (int i = 0; i < RN; ++i)
 #pragma unroll
         for (int j = 0; j < RM; ++j) {
           const int m = m0 + j * 16 + frow, n = n0 + i * 16 + 4 * fq;
-          f4_t v = acc[i][j] + b4[i];
+          f4_t v = acc[i][j] * row_scale(j) + b4[i];
           acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
           // pin v in front of the divergent tail guard: hipcc otherwise sinks the MFMA that produces acc[i][j] into
           // the guarded block, where it would run with a partial EXEC mask (wrong A/B rows from the masked lanes)
@@ -253,11 +267,12 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           const int j = jb + jj;
+          const float sj = row_scale(j);
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
             for (int il = 0; il < 2; ++il) {
-              *(f4_t*)(scr + frow * SCR_STR + il * 64 + fq * 16) = acc[hf * 2 + il][j] + b4[hf * 2 + il];
+              *(f4_t*)(scr + frow * SCR_STR + il * 64 + fq * 16) = acc[hf * 2 + il][j] * sj + b4[hf * 2 + il];
               acc[hf * 2 + il][j] = f4_t{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -277,9 +292,10 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 #pragma unroll
       for (int j = 0; j < RM; ++j) {
         h4_t lo4[RN];
+        const float sj = row_scale(j);
 #pragma unroll
         for (int i = 0; i < RN; ++i) {
-          f4_t v = acc[i][j] + b4[i];
+          f4_t v = acc[i][j] * sj + b4[i];
           acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
           if constexpr (EPI == ZK_EPI_GELU) {
             v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
@@ -401,7 +417,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 
 template <int EPI>
 void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
-  constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144;
+  constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144 + 8 * 512;
   auto k = gemm_c8_kernel<EPI>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }

@@ -15,7 +15,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t row_stride,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int rows, half_t* o_hi,
-                                                        half_t* o_lo, int lo_fmt, float eps) {
+                                                        half_t* o_lo, int lo_fmt, int32_t* rowexp, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -37,16 +37,35 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
   const float var = wave_sum(q) * (1.0f / ZK_HIDDEN);
   const float rstd = 1.0f / sqrtf(var + eps);
+  float y3[3][4];
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = i * 256 + lane * 4;
     const f4_t g = *(const f4_t*)(gamma + c);
     const f4_t b = *(const f4_t*)(beta + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      y3[i][j] = fmaf((v[i][j] - mean) * rstd, g[j], b[j]);
+      amax = fmaxf(amax, fabsf(y3[i][j]));
+    }
+  }
+  float rs = 1.0f;      // row scale 2^-s of the ZK_F16C8 planes (zk_planes::rowexp)
+  if (rowexp) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const int sx = zk_row_exponent(amax);
+    rs = ldexpf(1.0f, -sx);
+    if (lane == 0) rowexp[row] = sx;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
     h4_t hi;
     float y[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      y[j] = fmaf((v[i][j] - mean) * rstd, g[j], b[j]);
+      y[j] = y3[i][j] * rs;
       hi[j] = (half_t)y[j];
     }
     *(h4_t*)(o_hi + (size_t)row * ZK_HIDDEN + c) = hi;
@@ -60,5 +79,5 @@ void zk_launch_layernorm(const float* x, int64_t row_stride, const float* gamma,
                          zk_planes out, float eps, hipStream_t s) {
   if (rows <= 0) return;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, gamma, beta, rows,
-                     out.hi, out.lo, out.lo_fmt, eps);
+                     out.hi, out.lo, out.lo_fmt, (out.lo && out.lo_fmt == ZK_LO_C8) ? out.rowexp : nullptr, eps);
 }

@@ -43,6 +43,35 @@ __global__ __launch_bounds__(256) void split_c8_kernel(const float* __restrict__
   out[i] = (unsigned short)__builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8(b0), zk_clamp_fp8(b1), 0, false);
 }
 
+// activations [rows, K] fp32 -> row-scaled planes (zk_planes::rowexp): one wave per row, two passes over the row
+__global__ __launch_bounds__(256) void split_rows_c8_kernel(const float* __restrict__ src, int rows, int K,
+                                                            half_t* __restrict__ hi, half_t* __restrict__ c8,
+                                                            int32_t* __restrict__ rowexp) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = src + (size_t)row * K;
+  float amax = 0.f;
+  for (int c = lane * 4; c < K; c += 256) {
+    const f4_t v = *(const f4_t*)(xr + c);
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const int sx = zk_row_exponent(amax);
+  const float rs = ldexpf(1.0f, -sx);
+  if (lane == 0) rowexp[row] = sx;
+  for (int c = lane * 4; c < K; c += 256) {
+    const f4_t v = *(const f4_t*)(xr + c);
+    const float y[4] = {v[0] * rs, v[1] * rs, v[2] * rs, v[3] * rs};
+    h4_t h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = (half_t)y[j];
+    *(h4_t*)(hi + (size_t)row * K + c) = h;
+    *(h4_t*)(c8 + (size_t)row * K + c) = zk_lo4(y, h, ZK_LO_C8);
+  }
+}
+
 // WAV sample decode + channel mean (load_audio, src/test_long_audio_windows_2stage.py:54-56): interleaved little-endian
 // samples -> one mono float32 per frame.  fmt: 1 = integer PCM (8 unsigned / 16 / 24 / 32 bit), 3 = IEEE float (32 / 64).
 // Scaling as torchaudio.load(normalize=True): x / 2^(bits-1) (8-bit: (x-128)/128); channel mean = fp32 sum in channel
@@ -113,6 +142,11 @@ void zk_launch_resample(const float* in, int64_t n_in, int orig, int neu, int wi
   if (n_out <= 0) return;
   hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, in, n_in, orig, neu,
                      width, kernels, klen, out, n_out);
+}
+
+void zk_launch_split_rows_c8(const float* src, int rows, int K, half_t* hi, half_t* c8, int32_t* rowexp, hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(split_rows_c8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, rows, K, hi, c8, rowexp);
 }
 
 void zk_launch_split_c8(const float* src, int64_t n, int w_exp, int is_weight, half_t* c8, hipStream_t s) {

@@ -44,11 +44,24 @@ struct zk_planes {
   half_t* hi;
   half_t* lo;  // nullptr in single-pass mode
   int lo_fmt;
+  // ZK_F16C8 activations only, optional: per-row power-of-two exponent s_m.  Both planes of row m then hold x·2^-s_m
+  // (largest |x| of the row in (112, 224]: the fp8 bytes use e4m3's whole range whatever the row's magnitude, nothing
+  // saturates at 448 and small rows keep their correction) and the consuming GEMM multiplies its accumulator row by
+  // 2^s_m in the epilogue — exact, and free in the k-loop.  nullptr: planes are unscaled.
+  int32_t* rowexp;
 };
 
 #define ZK_C8_SHIFT 11   // (x - hi) is scaled by 2^11 before the fp8 rounding: |x - hi| <= 2^-11 |x|
 
 #ifdef __HIPCC__
+// exponent s of a row whose largest magnitude is amax: amax·2^-s lies in (112, 224] (0 for an all-zero row)
+__device__ __forceinline__ int zk_row_exponent(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 0;
+  int e;
+  const float f = frexpf(amax, &e);      // amax = f·2^e, f in [0.5, 1)
+  int s = (f <= 0.875f) ? e - 8 : e - 7; // 224 = 0.875·2^8
+  return s < -40 ? -40 : (s > 40 ? 40 : s);
+}
 __device__ __forceinline__ float zk_clamp_fp8(float x) { return __builtin_fminf(__builtin_fmaxf(x, -448.f), 448.f); }
 // two consecutive elements (value v, its fp16 rounding h) -> one dword of two (lo8, x8) byte pairs (OCP e4m3, RNE)
 __device__ __forceinline__ unsigned zk_c8_pack2(float v0, float h0, float v1, float h1) {
@@ -78,6 +91,7 @@ struct zk_gemm_args {
   const half_t* w_hi;  // [N, K] weights (nn.Linear layout)
   const half_t* w_lo;
   const float* bias;   // [N]
+  const int32_t* x_rowexp;  // [M] or nullptr: row m of the x planes holds x·2^-x_rowexp[m] (zk_planes::rowexp)
   int M, N, K;
   // outputs
   half_t* o_hi;        // [M, N] (STORE / GELU)
@@ -118,4 +132,6 @@ void zk_launch_wav_decode(const unsigned char* raw, int64_t n_frames, int fmt, i
 void zk_launch_split_f32(const float* src, int64_t n, float scale, half_t* hi, half_t* lo, hipStream_t s);
 // weights: c8 plane = (fp8(w·2^e), fp8((w - fp16(w))·2^(e+11))) byte pairs; activations (is_weight = 0): (fp8((x-xh)·2^11), fp8(x))
 void zk_launch_split_c8(const float* src, int64_t n, int w_exp, int is_weight, half_t* c8, hipStream_t s);
+// activations [rows, K] fp32 -> row-scaled fp16 + c8 planes and the row exponents (zk_planes::rowexp); K % 4 == 0
+void zk_launch_split_rows_c8(const float* src, int rows, int K, half_t* hi, half_t* c8, int32_t* rowexp, hipStream_t s);
 void zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s);

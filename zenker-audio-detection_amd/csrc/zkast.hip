@@ -37,9 +37,10 @@ struct DevBuf {
 };
 
 struct PlaneBuf {
-  DevBuf hi, lo;
+  DevBuf hi, lo, rowexp;      // rowexp: allocated only for the LayerNorm outputs (zk_planes::rowexp)
   zk_planes get(bool split, int lo_fmt = ZK_LO_F16) const {
-    return zk_planes{hi.as<half_t>(), split ? lo.as<half_t>() : nullptr, lo_fmt};
+    return zk_planes{hi.as<half_t>(), split ? lo.as<half_t>() : nullptr, lo_fmt,
+                     (split && lo_fmt == ZK_LO_C8) ? rowexp.as<int32_t>() : nullptr};
   }
 };
 
@@ -95,6 +96,10 @@ struct zk_ctx {
   DevBuf feat;  // compact [n_windows, n_frames, 128] fp32
   int feat_windows = 0, feat_frames = 0;
 
+  // audio slot: the recording load_audio left on the device (zk_audio_load)
+  DevBuf audio_slot;
+  int64_t audio_slot_n = 0;
+
   // staging + workspace
   DevBuf st_in, st_out, st_idx, audio_dev, s1_logits, s2_logits, gate_idx, gate_cnt, tmp_f32;
   DevBuf hidden;
@@ -115,6 +120,10 @@ struct zk_ctx {
   double prof_ms[P_N] = {0};
   double prof_flops[P_N] = {0};
   int64_t prof_n[P_N] = {0};
+
+  // multi-GPU: RCCL communicator (comm.hip owns the object) and its host<->device staging
+  void* comm = nullptr;
+  DevBuf comm_stage[2];
 
   // debug tap
   int tap_layer = -2;
@@ -327,6 +336,7 @@ int ensure_workspace(zk_ctx* c, int windows, bool split) {
   };
   HIPCHK(c, pl(c->patchA, M * ZK_PATCH_K));
   HIPCHK(c, pl(c->xn, M * ZK_HIDDEN));
+  if (sp) HIPCHK(c, c->xn.rowexp.ensure(M * 4));
   HIPCHK(c, pl(c->qkv, M * 3 * ZK_HIDDEN));
   HIPCHK(c, pl(c->att, M * ZK_HIDDEN));
   HIPCHK(c, pl(c->mid, M * ZK_INTER));
@@ -334,6 +344,7 @@ int ensure_workspace(zk_ctx* c, int windows, bool split) {
   HIPCHK(c, c->hidden_s.ensure(Ms * ZK_HIDDEN * 4));
   HIPCHK(c, pl(c->att_s, Ms * ZK_HIDDEN));
   HIPCHK(c, pl(c->xn_s, Ms * ZK_HIDDEN));
+  if (sp) HIPCHK(c, c->xn_s.rowexp.ensure(Ms * 4));
   HIPCHK(c, pl(c->mid_s, Ms * ZK_INTER));
   c->ws_windows = w;
   c->ws_split = sp;
@@ -346,6 +357,7 @@ void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias,
   if (c->prof) c->prof_flops[cls] += 2.0 * M * (double)N * K;
   zk_gemm_args a;
   a.x_hi = x.hi; a.x_lo = x.lo; a.w_hi = w.hi; a.w_lo = (nsplit == ZK_F16C8) ? w.c8 : w.lo; a.bias = bias;
+  a.x_rowexp = (nsplit == ZK_F16C8) ? x.rowexp : nullptr;
   a.M = M; a.N = N; a.K = K;
   a.o_hi = out.hi; a.o_lo = (nsplit != ZK_F16) ? out.lo : nullptr;
   a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.w_exp = w.exp;
@@ -503,10 +515,20 @@ int check_stage(zk_ctx* c, int stage) {
 
 }  // namespace
 
+// ---- context accessors for comm.hip --------------------------------------------------------------------------------
+hipStream_t zk_ctx_stream(zk_ctx* c) { return c->stream; }
+int zk_ctx_device(zk_ctx* c) { return c->device; }
+int zk_ctx_fail(zk_ctx* c, int code, const char* msg) { return fail(c, code, "%s", msg); }
+void** zk_ctx_comm_slot(zk_ctx* c) { return &c->comm; }
+void* zk_ctx_stage_buf(zk_ctx* c, int which, size_t bytes) {
+  if (c->comm_stage[which & 1].ensure(bytes) != hipSuccess) { fail(c, ZK_E_NOMEM, "comm staging buffer of %zu bytes", bytes); return nullptr; }
+  return c->comm_stage[which & 1].p;
+}
+
 // =====================================================================================================================
 extern "C" {
 
-const char* zk_version(void) { return "zkast 0.1 (gfx950)"; }
+const char* zk_version(void) { return "zkast 0.2 (gfx950)"; }
 
 int zk_create(int device_id, zk_ctx** out) {
   if (!out) return fail(nullptr, ZK_E_ARG, "out is NULL");
@@ -547,14 +569,17 @@ void zk_destroy(zk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  (void)zk_comm_destroy(c);
+  c->comm_stage[0].release(); c->comm_stage[1].release();
   for (auto& m : c->model) m.release();
   for (void* p : {(void*)c->d_hann, (void*)c->d_tw, (void*)c->d_mel, (void*)c->d_mel_lo, (void*)c->d_mel_hi})
     if (p) (void)hipFree(p);
+  c->audio_slot.release();
   for (DevBuf* b : {&c->feat, &c->st_in, &c->st_out, &c->st_idx, &c->audio_dev, &c->s1_logits, &c->s2_logits, &c->gate_idx,
                     &c->gate_cnt, &c->tmp_f32, &c->hidden, &c->rs_kern, &c->tap})
     b->release();
   c->hidden_s.release();
-  for (PlaneBuf* b : {&c->patchA, &c->xn, &c->qkv, &c->att, &c->mid, &c->att_s, &c->xn_s, &c->mid_s}) { b->hi.release(); b->lo.release(); }
+  for (PlaneBuf* b : {&c->patchA, &c->xn, &c->qkv, &c->att, &c->mid, &c->att_s, &c->xn_s, &c->mid_s}) { b->hi.release(); b->lo.release(); b->rowexp.release(); }
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -676,7 +701,12 @@ int zk_model_set_fx(zk_ctx* c, int stage, float fx_mean, float fx_std) {
 int zk_logmel(zk_ctx* c, const float* audio, int64_t n_samples, int64_t first_start, int64_t hop, int32_t win,
               int32_t n_windows) {
   if (!c) return ZK_E_ARG;
-  if (!audio || n_samples <= 0) return fail(c, ZK_E_ARG, "audio is empty");
+  if (!audio) {      // the audio slot (zk_audio_load)
+    if (c->audio_slot_n <= 0) return fail(c, ZK_E_STATE, "audio is NULL and the audio slot is empty (zk_audio_load)");
+    audio = c->audio_slot.as<float>();
+    n_samples = c->audio_slot_n;
+  }
+  if (n_samples <= 0) return fail(c, ZK_E_ARG, "audio is empty");
   if (n_windows < 0 || hop < 0 || first_start < 0) return fail(c, ZK_E_ARG, "negative window geometry");
   const int nf = n_frames_for(win);
   if (nf <= 0) return fail(c, ZK_E_SHAPE, "window of %d samples is shorter than one 400-sample frame", win);
@@ -827,6 +857,49 @@ int zk_two_stage(zk_ctx* c, const float* audio, int64_t n_samples, int64_t first
   return ZK_OK;
 }
 
+static int64_t resampled_len(int64_t n_in, int32_t orig_sr, int32_t new_sr) {
+  int a = orig_sr, b = new_sr;
+  while (b) { int t = a % b; a = b; b = t; }
+  const int64_t orig = orig_sr / a, neu = new_sr / a;
+  return (neu * n_in + orig - 1) / orig;
+}
+
+int zk_audio_load(zk_ctx* c, const void* data, int64_t n_bytes, int32_t format_tag, int32_t bits, int32_t channels,
+                  int32_t sr, int32_t target_sr, int64_t* n_samples_out) {
+  if (!c || !data) return ZK_E_ARG;
+  if (channels < 1 || bits < 8 || sr <= 0 || target_sr <= 0) return fail(c, ZK_E_ARG, "bad audio format");
+  const int64_t n_frames = n_bytes / ((int64_t)channels * (bits / 8));
+  c->audio_slot_n = 0;
+  if (n_samples_out) *n_samples_out = 0;
+  if (n_frames <= 0) return ZK_OK;
+  const bool was_async = c->async;
+  c->async = true;      // one sync at the end: upload -> decode -> resample stay queued on the stream
+  int rc;
+  if (sr == target_sr) {
+    HIPCHK(c, c->audio_slot.ensure((size_t)n_frames * 4));
+    rc = zk_wav_decode(c, data, n_bytes, format_tag, bits, channels, c->audio_slot.as<float>());
+    if (!rc) c->audio_slot_n = n_frames;
+  } else {
+    const int64_t n_out = resampled_len(n_frames, sr, target_sr);
+    rc = hipSuccess == c->tmp_f32.ensure((size_t)n_frames * 4) && hipSuccess == c->audio_slot.ensure((size_t)n_out * 4)
+             ? ZK_OK : fail(c, ZK_E_NOMEM, "audio buffers");
+    if (!rc) rc = zk_wav_decode(c, data, n_bytes, format_tag, bits, channels, c->tmp_f32.as<float>());
+    if (!rc) rc = zk_resample(c, c->tmp_f32.as<float>(), n_frames, sr, target_sr, c->audio_slot.as<float>(), n_out);
+    if (!rc) c->audio_slot_n = n_out;
+  }
+  c->async = was_async;
+  if (rc) return rc;
+  if (n_samples_out) *n_samples_out = c->audio_slot_n;
+  return finish(c);
+}
+
+int zk_audio_get(zk_ctx* c, float* out, int64_t* n_samples) {
+  if (!c) return ZK_E_ARG;
+  if (n_samples) *n_samples = c->audio_slot_n;
+  if (out && c->audio_slot_n > 0) return from_device(c, c->audio_slot.p, out, (size_t)c->audio_slot_n * 4);
+  return ZK_OK;
+}
+
 int zk_wav_decode(zk_ctx* c, const void* data, int64_t n_bytes, int32_t format_tag, int32_t bits, int32_t channels, float* out) {
   if (!c || !data || !out) return ZK_E_ARG;
   const bool ok = (format_tag == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32)) ||
@@ -940,25 +1013,35 @@ int zk_test_layernorm(zk_ctx* c, const float* x, const float* gamma, const float
   if (!c) return ZK_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)rows * ZK_HIDDEN;
-  float *dx, *dg, *db; half_t *hi, *lo;
+  float *dx, *dg, *db; half_t *hi, *lo; int32_t* dexp;
   HIPCHK(c, hipMalloc((void**)&dx, n * 4)); HIPCHK(c, hipMalloc((void**)&dg, ZK_HIDDEN * 4)); HIPCHK(c, hipMalloc((void**)&db, ZK_HIDDEN * 4));
   HIPCHK(c, hipMalloc((void**)&hi, n * 2)); HIPCHK(c, hipMalloc((void**)&lo, n * 2));
+  HIPCHK(c, hipMalloc((void**)&dexp, (size_t)rows * 4)); HIPCHK(c, hipMemset(dexp, 0, (size_t)rows * 4));
   HIPCHK(c, hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dg, gamma, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(db, beta, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
   const int lf = nsplit == ZK_F16C8 ? ZK_LO_C8 : ZK_LO_F16;
-  zk_launch_layernorm(dx, ZK_HIDDEN, dg, db, rows, zk_planes{hi, nsplit != ZK_F16 ? lo : nullptr, lf}, eps, c->stream);
+  zk_launch_layernorm(dx, ZK_HIDDEN, dg, db, rows, zk_planes{hi, nsplit != ZK_F16 ? lo : nullptr, lf, dexp}, eps, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<uint16_t> h(n), l(n, 0);
+  std::vector<int32_t> ex(rows, 0);
   HIPCHK(c, hipMemcpy(h.data(), hi, n * 2, hipMemcpyDeviceToHost));
   if (nsplit != ZK_F16) HIPCHK(c, hipMemcpy(l.data(), lo, n * 2, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(ex.data(), dexp, (size_t)rows * 4, hipMemcpyDeviceToHost));
   size_t bad = 0;
-  for (size_t i = 0; i < n; ++i) {
-    out[i] = half_bits_to_float(h[i]) + (nsplit != ZK_F16 ? lo_entry_to_float(l[i], lf) : 0.f);
-    if (lf == ZK_LO_C8 && !c8_value_byte_ok(l[i], out[i])) ++bad;
+  for (size_t i = 0; i < n; ++i) {      // planes hold y·2^-s of the row (s = 0 outside ZK_F16C8)
+    const float scaled = half_bits_to_float(h[i]) + (nsplit != ZK_F16 ? lo_entry_to_float(l[i], lf) : 0.f);
+    if (lf == ZK_LO_C8 && !c8_value_byte_ok(l[i], scaled)) ++bad;
+    out[i] = ldexpf(scaled, ex[i / ZK_HIDDEN]);
   }
-  (void)hipFree(dx); (void)hipFree(dg); (void)hipFree(db); (void)hipFree(hi); (void)hipFree(lo);
-  if (bad) return fail(c, ZK_E_STATE, "layernorm c8 plane: %zu value bytes are not the fp8 rounding of the output", bad);
+  if (lf == ZK_LO_C8)      // the row's largest plane entry must sit in (112, 224]
+    for (int r = 0; r < rows; ++r) {
+      float mx = 0.f;
+      for (int k = 0; k < ZK_HIDDEN; ++k) mx = fmaxf(mx, fabsf(half_bits_to_float(h[(size_t)r * ZK_HIDDEN + k])));
+      if (mx > 0.f && !(mx > 111.9f && mx <= 224.1f)) ++bad;
+    }
+  (void)hipFree(dx); (void)hipFree(dg); (void)hipFree(db); (void)hipFree(hi); (void)hipFree(lo); (void)hipFree(dexp);
+  if (bad) return fail(c, ZK_E_STATE, "layernorm c8 plane: %zu value bytes are not the fp8 rounding of the (row-scaled) output / rows off (112, 224]", bad);
   return ZK_OK;
 }
 
@@ -974,6 +1057,7 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   const size_t orows = epi == ZK_EPI_PATCH ? (size_t)(M / ZK_NPATCH) * ZK_SEQ : (size_t)M;
   const size_t no = orows * N;
   float *dx, *dw, *dbias, *dres = nullptr, *dpos = nullptr; half_t *xh, *xl, *wh, *wl, *oh = nullptr, *ol = nullptr;
+  int32_t* dexp = nullptr;
   HIPCHK(c, hipMalloc((void**)&dx, nx * 4)); HIPCHK(c, hipMalloc((void**)&dw, nw * 4)); HIPCHK(c, hipMalloc((void**)&dbias, (size_t)N * 4));
   // x planes are padded by one 256-row tile (the kernels clamp their M-tail rows to M-1; the pad only keeps a mistake
   // in that clamp from faulting)
@@ -988,7 +1072,8 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   int w_exp = 0;
   if (nsplit == ZK_F16C8) {      // lo planes become c8 byte pairs
     w_exp = c8_exponent(w, nw);
-    zk_launch_split_c8(dx, (int64_t)nx, 0, 0, xl, c->stream);
+    HIPCHK(c, hipMalloc((void**)&dexp, (size_t)(M + 256) * 4)); HIPCHK(c, hipMemset(dexp, 0, (size_t)(M + 256) * 4));
+    zk_launch_split_rows_c8(dx, M, K, xh, xl, dexp, c->stream);      // row-scaled planes, as LayerNorm writes them
     zk_launch_split_c8(dw, (int64_t)nw, w_exp, 1, wl, c->stream);
   }
   if (epi == ZK_EPI_RESID || epi == ZK_EPI_PATCH) {
@@ -1001,6 +1086,7 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   }
   zk_gemm_args a;
   a.x_hi = xh; a.x_lo = nsplit != ZK_F16 ? xl : nullptr; a.w_hi = wh; a.w_lo = nsplit != ZK_F16 ? wl : nullptr; a.bias = dbias;
+  a.x_rowexp = dexp;
   a.M = M; a.N = N; a.K = K; a.o_hi = oh; a.o_lo = nsplit != ZK_F16 ? ol : nullptr; a.resid = dres; a.pos = dpos; a.lo_n_limit = N;
   a.w_exp = w_exp;
   if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
@@ -1020,7 +1106,7 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
     }
     if (bad) return fail(c, ZK_E_STATE, "gemm GELU c8 plane: %zu value bytes are not the fp8 rounding of the output", bad);
   }
-  for (void* p : {(void*)dx, (void*)dw, (void*)dbias, (void*)dres, (void*)dpos, (void*)xh, (void*)xl, (void*)wh, (void*)wl, (void*)oh, (void*)ol})
+  for (void* p : {(void*)dx, (void*)dw, (void*)dbias, (void*)dres, (void*)dpos, (void*)xh, (void*)xl, (void*)wh, (void*)wl, (void*)oh, (void*)ol, (void*)dexp})
     if (p) (void)hipFree(p);
   return ZK_OK;
 }

@@ -50,14 +50,27 @@ def resolve_thresholds(threshold_config: Optional[dict], fold: int) -> Dict[str,
     return out
 
 
+def shard_patients(patients: List[str], rank: int, world: int) -> List[str]:
+    """Patients are the independent unit of the batch ("shard by patient/file first"): rank r takes every
+    world-th patient of the list, which spreads long and short recordings of a sorted id list evenly."""
+    return list(patients[rank::world])
+
+
 def run_batch(patients: List[str], long_audio_root: str, model_s1, fx_s1, model_s2, fx_s2, output_dir: str = "outputs",
-              pattern: str = "*.wav", force: bool = False, dry_run: bool = False, log=print,
+              pattern: str = "*.wav", force: bool = False, dry_run: bool = False, log=print, rank: int = 0,
+              world: int = 1, gather_bytes=None, summaries: Optional[Dict[str, Any]] = None,
               **opts: Any) -> Dict[str, str]:
     """The patient loop of main() (:258-292).  opts: window_sec, hop_sec, stage1_threshold, stage2_threshold,
-    stage1_forward_min_prob, stage2_argmax, stage1_model_root, stage2_model_root.  Returns {pid: status}."""
+    stage1_forward_min_prob, stage2_argmax, stage1_model_root, stage2_model_root.  Returns {pid: status}.
+
+    world > 1: this rank runs `shard_patients(patients, rank, world)` on its own GPU (the models stay resident, the
+    per-patient JSON files go to the shared output directory exactly as in the single-process run) and the statuses —
+    and, when `summaries` is given, each patient's "aggregate" block, which is all utils/aggregate_2stage_results.py
+    reads (:119-129) — are gathered at the end, so every rank returns the full table."""
     os.makedirs(output_dir, exist_ok=True)
     status = {}
-    for pid in patients:
+    local_summ: Dict[str, Any] = {}
+    for pid in shard_patients(patients, rank, world):
         expected_json = os.path.join(output_dir, f"{pid}_2stage.json")
         if os.path.exists(expected_json) and not force:
             log(f"[SKIP] {pid} (exists: {expected_json})")
@@ -72,11 +85,22 @@ def run_batch(patients: List[str], long_audio_root: str, model_s1, fx_s1, model_
             output = pl.run_patient(files, model_s1, fx_s1, model_s2, fx_s2, dict(opts))
             with open(expected_json, "w") as f:
                 json.dump(output, f, indent=2)
+            local_summ[pid] = output.get("aggregate")
             log(f"[DONE] {pid} OK")
             status[pid] = "ok"
         except Exception as e:  # one bad patient must not stop the batch (:286-289)
             log(f"[ERROR] patient {pid}: {type(e).__name__}: {e}")
             status[pid] = "error"
+    if world > 1 and gather_bytes is not None:
+        status_all, summ_all = {}, {}
+        for blob in gather_bytes(json.dumps({"status": status, "summ": local_summ}).encode()):
+            d = json.loads(blob.decode())
+            status_all.update(d["status"])
+            summ_all.update(d["summ"])
+        status = {pid: status_all[pid] for pid in patients if pid in status_all}      # list order, as one process reports it
+        local_summ = summ_all
+    if summaries is not None:
+        summaries.update(local_summ)
     log("Batch complete.")
     return status
 
@@ -120,10 +144,30 @@ def main(argv=None):
     if args.dry_run:
         return run_batch(patients, args.long_audio_root, None, None, None, None, args.output_dir or "outputs",
                          args.pattern, args.force, True, **opts)
-    fx_s1, model_s1 = pl.load_stage_model(s1, ["Idle", "Swallow"], 0, args.compute_mode)
-    fx_s2, model_s2 = pl.load_stage_model(s2, ["Healthy", "Zenker"], 1, args.compute_mode)
-    return run_batch(patients, args.long_audio_root, model_s1, fx_s1, model_s2, fx_s2, args.output_dir or "outputs",
-                     args.pattern, args.force, False, **opts)
+    # one process per GPU (python -m torch.distributed.run --nproc-per-node N -m zkast.batch ...): the patient list is
+    # sharded across the ranks, each rank keeps both models resident on its own GPU; torch.distributed (gloo) only
+    # ships the RCCL unique id, the final gather of the per-patient records runs through the C ABI
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    device = int(os.environ.get("LOCAL_RANK", "0"))
+    fx_s1, model_s1 = pl.load_stage_model(s1, ["Idle", "Swallow"], 0, args.compute_mode, device)
+    fx_s2, model_s2 = pl.load_stage_model(s2, ["Healthy", "Zenker"], 1, args.compute_mode, device)
+    gather = None
+    if world > 1:
+        import torch.distributed as tdist
+        from . import dist as zdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group("gloo", rank=rank, world_size=world)
+        zdist.init_comm(model_s1._ctx, rank, world)
+        gather = model_s1._ctx.allgather_bytes
+    try:
+        return run_batch(patients, args.long_audio_root, model_s1, fx_s1, model_s2, fx_s2,
+                         args.output_dir or "outputs", args.pattern, args.force, False,
+                         log=print if rank == 0 else (lambda *_: None), rank=rank, world=world, gather_bytes=gather,
+                         **opts)
+    finally:
+        if world > 1:
+            model_s1._ctx.comm_destroy()
+            tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -2,13 +2,15 @@
 
 The reference is single-process / single-device; a long recording is a batch of independent 1 s windows
 (src/test_long_audio_windows_2stage.py:62-75), so the N windows are partitioned into contiguous ranges, each rank
-runs stage 1 on its range, the per-window logits (N x 2 fp32 — a few KB) are all-gathered over RCCL/xGMI
-(`torch.distributed`, backend "nccl" on the GPU box, "gloo" in the CPU tests), every rank derives the identical
-gate, the K gated windows are re-partitioned evenly (swallows cluster in time, so re-using the stage-1 partition would
-imbalance stage 2) and the stage-2 logits are all-gathered the same way.  No other data-path collective exists.
+runs stage 1 on its range, the per-window logits (N x 2 fp32 — a few KB) are all-gathered over RCCL/xGMI, every rank
+derives the identical gate, the K gated windows are re-partitioned evenly (swallows cluster in time, so re-using the
+stage-1 partition would imbalance stage 2) and the stage-2 logits are all-gathered the same way.  No other data-path
+collective exists.
 
-The compute is injected as two callables so that the partition / gather / gate logic is testable on CPU (gloo,
-world_size 2) without a GPU; `ZkShardedCascade` binds them to the HIP path.
+The GPU path gathers through the C ABI (`zk_allgather_logits`: RCCL inside libzkast.so on the context's stream; the
+host only ships the 128-byte unique id once, see `init_comm`).  The compute and the gather are injected as callables so
+that the partition / gather / gate logic is testable on CPU (`torch.distributed` gloo, world_size 2) without a GPU;
+`ZkShardedCascade` binds them to the HIP path.
 """
 from __future__ import annotations
 
@@ -29,23 +31,48 @@ def _dist():
     return dist
 
 
-def all_gather_rows(local: np.ndarray, n_total: int, world: int, device=None) -> np.ndarray:
+def init_comm(ctx, rank: int, world: int, exchange=None) -> None:
+    """Bind an RCCL communicator to the context.  `exchange(payload_or_None) -> bytes` ships rank 0's 128-byte unique
+    id to every rank over a host channel; default: a broadcast on the already initialised torch.distributed group (the
+    only thing torch.distributed is used for on the GPU path)."""
+    from . import lib
+    if world == 1:
+        ctx.comm_init(0, 1, None)
+        return
+    uid = lib.comm_unique_id() if rank == 0 else None
+    if exchange is None:
+        def exchange(payload):
+            box = [payload]
+            _dist().broadcast_object_list(box, src=0)
+            return box[0]
+    ctx.comm_init(rank, world, exchange(uid))
+
+
+def all_gather_rows(local: np.ndarray, n_total: int, world: int, device=None, ctx=None) -> np.ndarray:
     """all-gather of contiguous row shards produced with shard_range; returns (n_total, cols) on every rank.
-    Shards are padded to the largest count so that ONE fixed-size collective is issued."""
-    import torch
-    dist = _dist()
+    Shards are padded to the largest count so that ONE fixed-size collective is issued.  ctx: gather through the C ABI
+    (RCCL in libzkast.so); otherwise `torch.distributed` (gloo in the CPU tests)."""
     cols = local.shape[1] if local.ndim == 2 else 2
-    if world == 1 or not (dist.is_available() and dist.is_initialized()):
-        return np.ascontiguousarray(local, dtype=np.float32).reshape(n_total, cols)
     per = (n_total + world - 1) // world
-    buf = torch.zeros((per, cols), dtype=torch.float32)
-    if local.shape[0]:
-        buf[: local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
-    if device is not None:
-        buf = buf.to(device)
-    out = torch.empty((world * per, cols), dtype=torch.float32, device=buf.device)
-    dist.all_gather_into_tensor(out, buf)
-    out = out.cpu().numpy().reshape(world, per, cols)
+    if ctx is not None and world > 1:
+        buf = np.zeros((per, cols), np.float32)
+        if local.shape[0]:
+            buf[: local.shape[0]] = np.ascontiguousarray(local, dtype=np.float32)
+        out = np.empty((world, per, cols), np.float32)
+        ctx.allgather_logits(buf, per, cols, out)
+    else:
+        import torch
+        dist = _dist()
+        if world == 1 or not (dist.is_available() and dist.is_initialized()):
+            return np.ascontiguousarray(local, dtype=np.float32).reshape(n_total, cols)
+        buf = torch.zeros((per, cols), dtype=torch.float32)
+        if local.shape[0]:
+            buf[: local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
+        if device is not None:
+            buf = buf.to(device)
+        out = torch.empty((world * per, cols), dtype=torch.float32, device=buf.device)
+        dist.all_gather_into_tensor(out, buf)
+        out = out.cpu().numpy().reshape(world, per, cols)
     parts = []
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)
@@ -72,39 +99,62 @@ def gate_indices(s1_probs: np.ndarray, thr1: float, fwd_min_prob: Optional[float
 
 def sharded_cascade(n_windows: int, stage_logits: Callable[[int, np.ndarray], np.ndarray], rank: int, world: int,
                     thr1: float, fwd_min_prob: Optional[float] = None, device=None,
-                    softmax: Callable[[np.ndarray], np.ndarray] = softmax_np):
+                    softmax: Callable[[np.ndarray], np.ndarray] = softmax_np, ctx=None):
     """stage_logits(stage, win_idx int32[]) -> (len(win_idx), 2) logits of those windows, computed locally.
     Returns (s1_logits (N,2), swallow_idx (K,), s2_logits (K,2)) — identical on every rank."""
     lo, hi = shard_range(n_windows, rank, world)
     mine = np.arange(lo, hi, dtype=np.int32)
     l1 = stage_logits(0, mine) if hi > lo else np.zeros((0, 2), np.float32)
-    s1 = all_gather_rows(l1, n_windows, world, device)
+    s1 = all_gather_rows(l1, n_windows, world, device, ctx)
     idx = gate_indices(softmax(s1) if n_windows else np.zeros((0, 2), np.float32), thr1, fwd_min_prob)
     k = int(idx.shape[0])
     klo, khi = shard_range(k, rank, world)
     l2 = stage_logits(1, idx[klo:khi]) if khi > klo else np.zeros((0, 2), np.float32)
-    s2 = all_gather_rows(l2, k, world, device) if k else np.zeros((0, 2), np.float32)
+    s2 = all_gather_rows(l2, k, world, device, ctx) if k else np.zeros((0, 2), np.float32)
     return s1, idx, s2
 
 
 class ZkShardedCascade:
-    """Binds sharded_cascade to the HIP path for one recording: every rank computes the (cheap, 7.6 MFLOP/window)
-    log-mel of the whole recording into its own feature slot, then runs the two AST forwards on its shards."""
+    """Binds sharded_cascade to the HIP path for one recording.  A rank uploads and log-mels only the audio its windows
+    need: `audio[lo*hop : (hi-1)*hop + win]` for its stage-1 range [lo, hi) (adjacent ranks overlap by
+    win - hop samples), and, when its share of the re-partitioned gated windows leaves that range, the slice that
+    covers the share.  The logit gathers run through `zk_allgather_logits` when the context has a communicator
+    (`init_comm`), else through `torch.distributed`."""
 
-    def __init__(self, model_s1, fx_s1, model_s2, fx_s2, rank: int, world: int, device=None):
+    def __init__(self, model_s1, fx_s1, model_s2, fx_s2, rank: int, world: int, device=None, use_ctx_comm=None):
         self.m = (model_s1, model_s2)
         self.fx = (fx_s1, fx_s2)
         self.rank, self.world, self.device = rank, world, device
+        ctx = model_s1._ctx
+        if use_ctx_comm is None:
+            use_ctx_comm = ctx.comm_info()[1] == world and world > 1
+        self.comm_ctx = ctx if use_ctx_comm else None
+        self.h2d_samples = 0          # audio samples uploaded by the last call (what config 4 counts per rank)
 
     def __call__(self, audio: np.ndarray, window_sec=1.0, hop_sec=0.5, thr1=0.5, fwd_min_prob=None):
         from .pipeline import window_geometry
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
         n, win, hop = window_geometry(len(audio), window_sec, hop_sec)
         ctx = self.m[0]._ctx
         for m, fx in zip(self.m, self.fx):
             m.bind_feature_extractor(fx)
-        ctx.logmel(np.ascontiguousarray(audio, dtype=np.float32), len(audio), 0, hop, win, n)
+        self.h2d_samples = 0
+        slot = [0, 0]                 # window range [lo, hi) currently in the feature slot
+
+        def fill_slot(lo, hi):
+            if lo >= slot[0] and hi <= slot[1]:
+                return
+            a0 = lo * hop
+            a1 = min(len(audio), (hi - 1) * hop + win)      # a recording shorter than one window is zero-padded
+            piece = audio[a0:a1]
+            ctx.logmel(piece, len(piece), 0, hop, win, hi - lo)
+            self.h2d_samples += len(piece)
+            slot[0], slot[1] = lo, hi
 
         def stage_logits(stage, win_idx):
-            return self.m[stage].forward_from_slot(len(win_idx), win_idx)
+            win_idx = np.asarray(win_idx, np.int32)
+            fill_slot(int(win_idx[0]), int(win_idx[-1]) + 1)
+            return self.m[stage].forward_from_slot(len(win_idx), win_idx - np.int32(slot[0]))
 
-        return sharded_cascade(n, stage_logits, self.rank, self.world, thr1, fwd_min_prob, self.device, ctx.softmax)
+        return sharded_cascade(n, stage_logits, self.rank, self.world, thr1, fwd_min_prob, self.device, ctx.softmax,
+                               self.comm_ctx)

@@ -28,7 +28,8 @@ SYMBOLS = [
     "zk_create", "zk_destroy", "zk_last_error", "zk_set_stream", "zk_set_async", "zk_synchronize",
     "zk_set_micro_batch", "zk_set_prune_last_layer", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_fx",
     "zk_logmel", "zk_features_expand", "zk_features_get", "zk_ast_forward", "zk_softmax", "zk_two_stage", "zk_gate",
-    "zk_resample", "zk_wav_decode", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_prof_get_flops", "zk_debug_set_tap", "zk_debug_get_tap",
+    "zk_comm_unique_id", "zk_comm_init", "zk_comm_destroy", "zk_comm_info", "zk_allgather_logits", "zk_comm_allgather_bytes",
+    "zk_resample", "zk_wav_decode", "zk_audio_load", "zk_audio_get", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_prof_get_flops", "zk_debug_set_tap", "zk_debug_get_tap",
     "zk_test_layernorm", "zk_test_gemm", "zk_test_attention", "zk_test_split_c8",
 ]
 
@@ -92,7 +93,15 @@ def load_library() -> C.CDLL:
             "zk_softmax": (C.c_int, [vp, vp, i32, i32, vp]),
             "zk_two_stage": (C.c_int, [vp, vp, i64, i64, i64, i32, i32, f32, f32, vp, vp, vp, vp]),
             "zk_gate": (C.c_int, [vp, vp, i32, f32, f32, vp, vp, vp]),
+            "zk_comm_unique_id": (C.c_int, [vp]),
+            "zk_comm_init": (C.c_int, [vp, i32, i32, vp]),
+            "zk_comm_destroy": (C.c_int, [vp]),
+            "zk_comm_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
+            "zk_allgather_logits": (C.c_int, [vp, vp, i32, i32, vp]),
+            "zk_comm_allgather_bytes": (C.c_int, [vp, vp, i64, vp]),
             "zk_resample": (C.c_int, [vp, vp, i64, i32, i32, vp, i64]),
+            "zk_audio_load": (C.c_int, [vp, vp, i64, i32, i32, i32, i32, i32, C.POINTER(i64)]),
+            "zk_audio_get": (C.c_int, [vp, vp, C.POINTER(i64)]),
             "zk_prof_begin": (C.c_int, [vp]),
             "zk_prof_end": (C.c_int, [vp]),
             "zk_prof_get": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
@@ -111,6 +120,15 @@ def load_library() -> C.CDLL:
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+def comm_unique_id() -> bytes:
+    """128-byte RCCL unique id (rank 0 creates it and ships it to the other ranks over any host channel)."""
+    buf = C.create_string_buffer(128)
+    rc = load_library().zk_comm_unique_id(buf)
+    if rc:
+        raise ZkError(f"zk_comm_unique_id failed ({rc}): RCCL (librccl.so.1) could not be loaded")
+    return buf.raw
 
 
 def _is_torch(x) -> bool:
@@ -288,6 +306,19 @@ class Context:
         k = cnt.value
         return s1, idx[:k].copy(), s2[:k].copy()
 
+    def two_stage_into(self, audio, n_samples, first_start, hop, win, n_windows, thr1, fwd_min_prob, s1_logits,
+                       swallow_idx, n_swallow, s2_logits):
+        """zk_two_stage with caller-provided outputs (numpy or torch, host or device): s1_logits (N,2), swallow_idx (N)
+        int32, n_swallow (>=1) int32, s2_logits (N,2).  Nothing but the gate count crosses PCIe when all are device."""
+        pa, _k0 = _ptr(audio)
+        p1, _k1 = _ptr(s1_logits)
+        pi, _k2 = _ptr(swallow_idx)
+        pc, _k3 = _ptr(n_swallow)
+        p2, _k4 = _ptr(s2_logits)
+        self._chk(self.lib.zk_two_stage(self.h, pa, int(n_samples), int(first_start), int(hop), int(win), int(n_windows),
+                                        float(thr1), -1.0 if fwd_min_prob is None else float(fwd_min_prob),
+                                        p1, pi, pc, p2), "zk_two_stage")
+
     def resample(self, audio: np.ndarray, orig_sr: int, new_sr: int) -> np.ndarray:
         audio = np.ascontiguousarray(audio, dtype=np.float32)
         g = int(np.gcd(orig_sr, new_sr))
@@ -307,6 +338,61 @@ class Context:
             self._chk(self.lib.zk_wav_decode(self.h, buf.ctypes.data, buf.size, int(format_tag), int(bits), int(channels),
                                              out.ctypes.data), "zk_wav_decode")
         return out
+
+    def audio_load(self, raw: bytes, format_tag: int, bits: int, channels: int, sr: int, target_sr: int) -> int:
+        """load_audio on the device: one upload of the data chunk, decode + channel mean + resample; the recording
+        stays in the context's audio slot (two_stage / logmel with audio=None).  Returns its length in samples."""
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        n = C.c_int64(0)
+        self._chk(self.lib.zk_audio_load(self.h, buf.ctypes.data, buf.size, int(format_tag), int(bits), int(channels),
+                                         int(sr), int(target_sr), C.byref(n)), "zk_audio_load")
+        return n.value
+
+    def audio_len(self) -> int:
+        n = C.c_int64(0)
+        self._chk(self.lib.zk_audio_get(self.h, None, C.byref(n)), "zk_audio_get")
+        return n.value
+
+    def audio_get(self) -> np.ndarray:
+        out = np.empty((self.audio_len(),), np.float32)
+        if out.size:
+            self._chk(self.lib.zk_audio_get(self.h, out.ctypes.data, None), "zk_audio_get")
+        return out
+
+    # ---- multi-GPU (RCCL behind the C ABI) ----
+    def comm_init(self, rank: int, world: int, unique_id: bytes | None):
+        """Collective: bind an RCCL communicator to this context (world 1 needs no id and no RCCL)."""
+        buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        self._chk(self.lib.zk_comm_init(self.h, int(rank), int(world), buf), "zk_comm_init")
+
+    def comm_destroy(self):
+        self._chk(self.lib.zk_comm_destroy(self.h), "zk_comm_destroy")
+
+    def comm_info(self):
+        r, w = C.c_int32(), C.c_int32()
+        self._chk(self.lib.zk_comm_info(self.h, C.byref(r), C.byref(w)), "zk_comm_info")
+        return r.value, w.value
+
+    def allgather_logits(self, local, rows_per_rank: int, cols: int, out):
+        """local (rows_per_rank, cols) fp32 -> out (world, rows_per_rank, cols); numpy or torch, host or device."""
+        pl_, _k1 = _ptr(local)
+        po, _k2 = _ptr(out)
+        self._chk(self.lib.zk_allgather_logits(self.h, pl_, int(rows_per_rank), int(cols), po), "zk_allgather_logits")
+
+    def allgather_bytes(self, payload: bytes) -> list:
+        """Every rank contributes `payload` (lengths may differ); returns the list of all ranks' payloads."""
+        _r, world = self.comm_info()
+        n = np.array([len(payload)], np.int64)
+        lens = np.zeros((world,), np.int64)
+        self._chk(self.lib.zk_comm_allgather_bytes(self.h, n.ctypes.data, 8, lens.ctypes.data), "zk_comm_allgather_bytes")
+        width = int(lens.max())
+        if width == 0:
+            return [b""] * world
+        send = np.zeros((width,), np.uint8)
+        send[: len(payload)] = np.frombuffer(payload, np.uint8)
+        recv = np.zeros((world, width), np.uint8)
+        self._chk(self.lib.zk_comm_allgather_bytes(self.h, send.ctypes.data, width, recv.ctypes.data), "zk_comm_allgather_bytes")
+        return [recv[r, : int(lens[r])].tobytes() for r in range(world)]
 
     # ---- measurement ----
     def prof_begin(self):

@@ -81,15 +81,18 @@ def write_wav_pcm16(path: str, audio: np.ndarray, sr: int):
                 struct.pack("<IHHIIHH", 16, 1, 1, sr, sr * 2, 2, 16) + b"data" + struct.pack("<I", len(pcm)) + pcm)
 
 
-def load_audio(path: str, target_sr: int = SAMPLING_RATE, device: int = 0) -> np.ndarray:
-    """src/test_long_audio_windows_2stage.py:53-59: load, mean over channels, resample to 16 kHz — sample decode,
-    channel mean and resampling all run on the GPU (zk_wav_decode, zk_resample); only the RIFF header is walked here."""
+def load_audio_to_device(path: str, target_sr: int = SAMPLING_RATE, device: int = 0) -> int:
+    """load_audio (src/test_long_audio_windows_2stage.py:53-59) that STAYS on the GPU: the RIFF header is walked here,
+    the data chunk goes up once, sample decode + channel mean + resampling run on the device (zk_audio_load) and the
+    recording is left in the context's audio slot for classify_recording(audio=None).  Returns its length."""
     tag, ch, sr, bits, raw = parse_wav(path)
-    ctx = _lib.get_context(device)
-    x = ctx.wav_decode(raw, tag, bits, ch)
-    if sr != target_sr:
-        x = ctx.resample(x, sr, target_sr)
-    return x
+    return _lib.get_context(device).audio_load(raw, tag, bits, ch, sr, target_sr)
+
+
+def load_audio(path: str, target_sr: int = SAMPLING_RATE, device: int = 0) -> np.ndarray:
+    """:53-59 with the reference's return contract (1-D np.float32 at 16 kHz): load_audio_to_device + one copy back."""
+    load_audio_to_device(path, target_sr, device)
+    return _lib.get_context(device).audio_get()
 
 
 def window_geometry(n_samples: int, window_sec: float, hop_sec: float, sr: int = SAMPLING_RATE):
@@ -229,14 +232,16 @@ def classify_recording(audio: np.ndarray, model_s1, fx_s1, model_s2, fx_s2, wind
                        stage1_label_order=("Idle", "Swallow"), stage2_label_order=("Healthy", "Zenker")):
     """The per-file body of main() (:301-348) as ONE library call (zk_two_stage): log-mel once, stage-1 forward,
     on-device gate + compaction, stage-2 forward on the gated windows re-normalised with stage 2's mean/std.
+    audio=None: the recording is the context's audio slot (load_audio_to_device) — nothing crosses PCIe but logits.
     Returns (summary dict, s1_probs, s1_preds, stage2_aligned_classes, stage2_results)."""
     ctx = model_s1._ctx
-    n, win, hop = window_geometry(len(audio), window_sec, hop_sec)
+    n_samples = ctx.audio_len() if audio is None else len(audio)
+    n, win, hop = window_geometry(n_samples, window_sec, hop_sec)
     model_s1.bind_feature_extractor(fx_s1)
     model_s2.bind_feature_extractor(fx_s2)
     s1_logits, swallow_indices, s2_logits = ctx.two_stage(
-        np.ascontiguousarray(audio, dtype=np.float32), len(audio), 0, hop, win, n, np.float32(stage1_threshold),
-        stage1_forward_min_prob)
+        None if audio is None else np.ascontiguousarray(audio, dtype=np.float32), n_samples, 0, hop, win, n,
+        np.float32(stage1_threshold), stage1_forward_min_prob)
     s1_probs = ctx.softmax(s1_logits)
     if s1_probs.ndim != 2 or s1_probs.shape[1] != 2:
         raise RuntimeError("Stage1 output shape unexpected; expected (N,2)")
@@ -280,7 +285,11 @@ def run_patient(files: List[str], model_s1, fx_s1, model_s2, fx_s2, args_like: D
     """The `output` dict main() writes as <pid>_2stage.json (:384-396), for two files (or in-memory recordings)."""
     per_file = {}
     for idx, path in enumerate(files):
-        audio = audios[idx] if audios is not None else load_audio(path)
+        if audios is not None:
+            audio = audios[idx]
+        else:      # file -> device once; decode, resample, log-mel and both forwards read it there
+            load_audio_to_device(path, device=getattr(model_s1, "_device", 0))
+            audio = None
         summary, *_ = classify_recording(
             audio, model_s1, fx_s1, model_s2, fx_s2, args_like.get("window_sec", 1.0), args_like.get("hop_sec", 0.5),
             args_like.get("stage1_threshold", 0.5), args_like.get("stage2_threshold", 0.5),

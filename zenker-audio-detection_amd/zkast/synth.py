@@ -96,7 +96,40 @@ WEIGHT_SETS = {
     "init": dict(mat=0.02, bias=0.02, emb=0.02, gamma=0.10, beta=0.05, head=0.05, patch=0.02),
     # wider matrices: peaked attention, residual growth, input-sensitive logits ("trained-like" scale)
     "wide": dict(mat=0.05, bias=0.05, emb=0.05, gamma=0.25, beta=0.10, head=0.10, patch=0.05),
+    # what a fine-tuned ViT/DeiT checkpoint looks like to a low-precision GEMM, which the uniform sets are not:
+    # heavy-tailed matrices (normal x log-normal scale mixture, kurtosis ~11, max|w| ~ 40-60 sigma) with log-normal
+    # per-output-row scales, LayerNorm gains with a handful of 4-8x outlier channels, and two "massive activation"
+    # residual channels (fc2 biases of +55 / -40 in layers 2 and 3) that every later LayerNorm has to carry
+    "heavy": dict(mat=0.03, bias=0.05, emb=0.05, gamma=0.25, beta=0.10, head=0.10, patch=0.05, heavy=True),
 }
+MASSIVE_CHANNELS = ((47, 55.0), (512, -40.0))      # (residual channel, fc2 bias) of the "heavy" set
+MASSIVE_LAYERS = (2, 3)
+
+
+def _normal_pair(seed: int, name: str, n: int):
+    """two independent standard normals per element (Box-Muller on splitmix64 uniforms)"""
+    u1 = splitmix64_uniform(seed ^ _fnv1a64(name + "#a"), n)
+    u2 = splitmix64_uniform(seed ^ _fnv1a64(name + "#b"), n)
+    r = np.sqrt(-2.0 * np.log1p(-u1))
+    return r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2)
+
+
+def _heavy_matrix(seed: int, name: str, shape, scale: float) -> np.ndarray:
+    n = int(np.prod(shape))
+    z, m = _normal_pair(seed, name, n)
+    tau = 0.55                                               # element-wise log-normal mixing: E[exp(2 tau m)] = exp(2 tau^2)
+    x = (z * np.exp(tau * m - tau * tau)).reshape(shape[0], -1)
+    rz, _ = _normal_pair(seed, name + "#row", shape[0])
+    x *= np.exp(0.4 * rz - 0.08)[:, None]                    # per-output-row scale, mean-square 1
+    return (x * scale).astype(np.float32).reshape(shape)
+
+
+def _heavy_gamma(seed: int, name: str, shape, jitter: float) -> np.ndarray:
+    g = _tensor(seed, name, shape, jitter, 1.0)
+    u = splitmix64_uniform(seed ^ _fnv1a64(name + "#out"), 12)
+    for j in range(6):                                       # six outlier channels per LayerNorm, gain 4..8
+        g[int(u[2 * j] * shape[0]) % shape[0]] = np.float32(4.0 + 4.0 * u[2 * j + 1])
+    return g
 
 
 def make_ast_weights(seed: int, weight_set: str = "wide", num_labels: int = NUM_LABELS, layers=None) -> dict:
@@ -108,20 +141,27 @@ def make_ast_weights(seed: int, weight_set: str = "wide", num_labels: int = NUM_
             li = int(name.split(".layers.")[1].split(".")[0])
             if li not in layers:
                 continue
+        heavy = bool(ws.get("heavy"))
         if name.endswith("layernorm.weight") or name.endswith("layernorm_before.weight") or name.endswith(
             "layernorm_after.weight"
         ):
-            out[name] = _tensor(seed, name, shape, ws["gamma"], 1.0)
+            out[name] = (_heavy_gamma if heavy and ".layers." in name else lambda a, b, c, d: _tensor(a, b, c, d, 1.0))(
+                seed, name, shape, ws["gamma"])
         elif "layernorm" in name and name.endswith(".bias"):
             out[name] = _tensor(seed, name, shape, ws["beta"])
         elif name.endswith(".bias"):
             out[name] = _tensor(seed, name, shape, ws["bias"])
+            if heavy and name.endswith("mlp.fc2.bias") and int(name.split(".layers.")[1].split(".")[0]) in MASSIVE_LAYERS:
+                for ch, val in MASSIVE_CHANNELS:
+                    out[name][ch] = np.float32(val)
         elif "embeddings.cls_token" in name or "distillation_token" in name or "position_embeddings" in name:
             out[name] = _tensor(seed, name, shape, ws["emb"])
         elif "patch_embeddings.projection.weight" in name:
             out[name] = _tensor(seed, name, shape, ws["patch"])
         elif name.startswith("classifier.dense"):
             out[name] = _tensor(seed, name, shape, ws["head"])
+        elif heavy:
+            out[name] = _heavy_matrix(seed, name, shape, ws["mat"])
         else:
             out[name] = _tensor(seed, name, shape, ws["mat"])
     return out
