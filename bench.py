@@ -53,15 +53,21 @@ def main():
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary f16x3 / single-pass fp16 measurements")
     ap.add_argument("--no-sweep", action="store_true", help="skip the g = 0.5 / 0.1 gate-rate lines")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed headline region (profiling runs): implies --no-fast --no-sweep --no-cpu, no configs[1] line")
     ap.add_argument("--cpu-windows", type=int, default=4,
                     help="CPU-baseline sample (default keeps the leg at ~20-30 s; SURVEY §8d's N=64 x 3: --cpu-windows 64 --cpu-repeats 3)")
     ap.add_argument("--cpu-repeats", type=int, default=1)
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_fast = args.no_sweep = args.no_cpu = True
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ZK_BENCH_ONE_GPU"):      # rehearsal of the N > 1 code path on a one-GPU box (all ranks on device 0)
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -79,7 +85,13 @@ def main():
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         tdist.init_process_group("gloo", rank=rank, world_size=world)
-        zdist.init_comm(ctx, rank, world)
+        try:
+            zdist.init_comm(ctx, rank, world)
+            collective = "RCCL all-gather of both logit tables through the C ABI (zk_allgather_logits)"
+        except lib.ZkError as e:      # never expected on the 8-GPU node; keep the scaling run alive and say so
+            print(f"[bench] rank {rank}: RCCL communicator failed ({e}); falling back to a host gather over gloo", file=sys.stderr)
+            collective = "FALLBACK: host all-gather over gloo (RCCL communicator could not be created)"
+    use_rccl = world > 1 and ctx.comm_info()[1] == world
 
     S1 = (-1.1509622, 3.5340312)
     S2 = (-6.5, 2.75)
@@ -125,20 +137,33 @@ def main():
 
     def step():
         ctx.two_stage_into(audio, n_samples, 0, hop, win, B, state["thr"], None, s1_logits, sw_idx, sw_cnt, s2_logits)
-        if world > 1:
+        if use_rccl:
             ctx.allgather_logits(s1_logits, B, 2, g1)
             ctx.allgather_logits(s2_logits, B, 2, g2)
+        elif world > 1:
+            h1, h2 = s1_logits.cpu(), s2_logits.cpu()
+            o1, o2 = torch.empty((world * B, 2)), torch.empty((world * B, 2))
+            tdist.all_gather_into_tensor(o1, h1)
+            tdist.all_gather_into_tensor(o2, h2)
+            g1.copy_(o1.view(world, B, 2)); g2.copy_(o2.view(world, B, 2))
+
+    def gather_bytes(b):
+        if use_rccl:
+            return ctx.allgather_bytes(b)
+        box = [None] * world
+        tdist.all_gather_object(box, b)
+        return box
 
     def barrier():
         torch.cuda.synchronize()
         ctx.synchronize()
         if world > 1:
-            ctx.allgather_bytes(b"\0")
+            gather_bytes(b"\0")
 
     def max_over_ranks(x):
         if world == 1:
             return x
-        return max(struct.unpack("<d", b)[0] for b in ctx.allgather_bytes(struct.pack("<d", x)))
+        return max(struct.unpack("<d", b)[0] for b in gather_bytes(struct.pack("<d", x)))
 
     def timed(steps, warmup, profile=False):
         for _ in range(warmup):
@@ -201,8 +226,7 @@ def main():
                                f"0.5 s, gate rate g={K / B:.2f}", "windows_per_gpu": B, "stage2_windows_per_gpu": K,
                    "micro_batch": args.micro_batch, "weights": "synthetic splitmix64 'wide' set (seeds 21/22), stage-1 "
                    f"swallow bias shifted by {shift:+.3f} so that thr1 alone sets the gate rate",
-                   "parallelism": f"window-sharded x{world}, RCCL all-gather of both logit tables through the C ABI"
-                                  if world > 1 else "single GPU"},
+                   "parallelism": f"window-sharded x{world}, {collective}" if world > 1 else "single GPU"},
         "roofline": roofline,
         "roofline_end_to_end": {"algorithmic_gflop_per_window_stage": FLOP_PER_WINDOW_STAGE / 1e9,
                                 "achieved_tflops_per_gpu": e2e_flops / 1e12, "frac_of_f16_dense_peak": e2e_flops / PEAK_F16_DENSE,
@@ -245,7 +269,7 @@ def main():
         m2.set_compute_mode(args.mode)
 
     # ---- BASELINE.json configs[1] as an extra line: batch 256, stage-1 only (log-mel + forward), all modes ----
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.headline_only:
         def stage1_b256(reps=3):
             n256 = min(256, B)
             ctx.logmel(audio, n_samples, 0, hop, win, n256); ctx.ast_forward(0, None, None, n256, s1_logits)
@@ -305,7 +329,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
-        ctx.comm_destroy()
+        if use_rccl:
+            ctx.comm_destroy()
         tdist.destroy_process_group()
 
 

@@ -1,44 +1,94 @@
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csv output (two separate passes) into HBM bytes per kernel launch.
-usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<note>"
+"""Aggregate rocprofv3 --pmc csv output into per-kernel, PER-LAUNCH-SHAPE rows (profiles/*_pmc_traffic.json).
+
+usage: python tools/pmc_traffic.py <out.json> "<note>" <counter_collection.csv> [<counter_collection.csv> ...]
+
+Every csv comes from its own `rocprofv3 --pmc ...` pass of the same command (FETCH_SIZE and WRITE_SIZE do not fit one
+pass; the SQ busy counters are a third).  Launches of one kernel symbol are split into shapes by their counter value
+(the RESID GEMM kernel serves both the O projection and FC2; the last layer's pruned launches are tiny): values within
+25 % of each other form one group, groups are matched across the passes by dispatch order.
 gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane streaming loads (MI355X_MICROARCH.md, HBM section), so
-hbm_bytes = (2*FETCH + WRITE) * 1024 (both counters are in KB)."""
-import csv, json, re, sys
+hbm_bytes = (2*FETCH + WRITE) * 1024 (both counters are in KB).  The file records the sha256 of the libzkast.so that was
+profiled; bench.py only quotes it for that build.
+"""
+import csv
+import hashlib
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def label(name):
     m = re.search(r"gemm_c8_kernel<(\d)", name)
     if m:
-        return {"0": "gemm_qkv(store)", "1": "gemm_fc1(gelu)", "2": "gemm_resid(o,fc2)", "3": "gemm_patch"}[m.group(1)]
+        return {"0": "gemm_qkv(store)", "1": "gemm_fc1(gelu)", "2": "gemm_resid", "3": "gemm_patch"}[m.group(1)]
     m = re.search(r"gemm_kernel<(\d), 256, 256, 32, 2, 4, \d, (\d)>", name)
-    if m:      # the 3-pass / 1-pass kernels (bench.py's configs[1] tail runs them too)
-        return {"1": "f16:", "3": "f16x3:"}[m.group(1)] + {"0": "gemm_qkv(store)", "1": "gemm_fc1(gelu)", "2": "gemm_resid(o,fc2)", "3": "gemm_patch"}[m.group(2)]
+    if m:
+        return {"1": "f16:", "3": "f16x3:"}[m.group(1)] + {"0": "gemm_qkv(store)", "1": "gemm_fc1(gelu)", "2": "gemm_resid", "3": "gemm_patch"}[m.group(2)]
     for k in ("attention", "layernorm", "logmel", "im2col", "head_kernel", "gather_tok01", "cls_rows", "gate", "expand"):
         if k in name:
             return k
     return name[:60]
 
 
-def load(path, counter):
-    agg = {}
-    with open(path) as f:
-        for r in csv.DictReader(f):
-            if r.get("Counter_Name") != counter:
-                continue
-            agg.setdefault(label(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+def load(paths):
+    """{counter: {kernel label: [values in dispatch order]}}"""
     out = {}
-    for k, v in agg.items():      # "full" launches: within 50 % of the largest (drops the pruned last-layer launches)
-        full = [x for x in v if x >= 0.5 * max(v)]
-        out[k] = [len(v), sum(v), max(v), sum(full) / len(full)]
+    for path in paths:
+        rows = list(csv.DictReader(open(path)))
+        rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0) or 0))
+        for r in rows:
+            out.setdefault(r["Counter_Name"], {}).setdefault(label(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
     return out
 
 
-fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "kernels": {}}
-for k in sorted(set(fetch) | set(write)):
-    f, w = fetch.get(k, [0, 0.0, 0.0, 0.0]), write.get(k, [0, 0.0, 0.0, 0.0])
-    n = max(f[0], w[0])
-    out["kernels"][k] = {"launches": n, "fetch_kb_avg_full": f[3], "write_kb_avg_full": w[3],
-                         "fetch_kb_max": f[2], "write_kb_max": w[2],
-                         "hbm_bytes_per_launch_corrected": (2 * f[3] + w[3]) * 1024}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+def shape_groups(values, tol=0.25):
+    """indices of the launches grouped by similar value (largest group first)"""
+    order = sorted(range(len(values)), key=lambda i: values[i])
+    groups, cur = [], [order[0]]
+    for i in order[1:]:
+        if values[i] <= values[cur[0]] * (1 + tol) + 1e-9:
+            cur.append(i)
+        else:
+            groups.append(cur); cur = [i]
+    groups.append(cur)
+    return sorted(groups, key=lambda g: -sum(values[i] for i in g))
+
+
+def main():
+    out_path, note, paths = sys.argv[1], sys.argv[2], sys.argv[3:]
+    data = load(paths)
+    so = os.path.join(ROOT, "zenker-audio-detection_amd", "zkast", "libzkast.so")
+    out = {"note": note, "libzkast_sha256": hashlib.sha256(open(so, "rb").read()).hexdigest(), "kernels": {}}
+    # shapes are told apart by what they READ (the O projection and FC2 write the same bytes, FC2 reads 4x the X)
+    key_counter = "FETCH_SIZE" if "FETCH_SIZE" in data else next(iter(data))
+    for kern, vals in sorted(data[key_counter].items()):
+        groups = shape_groups(vals)
+        for gi, g in enumerate(groups):
+            row = {"launches": len(g)}
+            for cname, per in data.items():
+                v = per.get(kern)
+                if v is None or len(v) != len(vals):
+                    continue
+                sel = [v[i] for i in g]
+                row[cname + "_avg"] = sum(sel) / len(sel)
+            if "FETCH_SIZE_avg" in row and "WRITE_SIZE_avg" in row:
+                row["hbm_bytes_per_launch_corrected"] = (2 * row["FETCH_SIZE_avg"] + row["WRITE_SIZE_avg"]) * 1024
+            # MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs (256 CUs x 4), SQ_BUSY_CYCLES
+            # those of the 32 shader engines (= 32 x the kernel's duration in shader clocks) -> busy share of one SIMD
+            if "SQ_VALU_MFMA_BUSY_CYCLES_avg" in row and row.get("SQ_BUSY_CYCLES_avg"):
+                row["mfma_util"] = row["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / (row["SQ_BUSY_CYCLES_avg"] * 32.0)
+            if row.get("GRBM_GUI_ACTIVE_avg"):
+                row["kernel_clocks"] = row["GRBM_GUI_ACTIVE_avg"] / 8.0      # the counter sums the 8 XCDs
+            name = kern if gi == 0 else f"{kern}#shape{gi + 1}"
+            if kern == "gemm_resid":      # larger traffic = FC2 (K = 3072), the other the O projection
+                name = {0: "gemm_fc2(resid)", 1: "gemm_o(resid)"}.get(gi, name)
+            out["kernels"][name] = row
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(json.dumps(out, indent=1)[:4000])
+
+
+if __name__ == "__main__":
+    main()

@@ -209,4 +209,38 @@ int zkp_fill_probe(int M, int N, int K, int depth, int fix, int rounds, float* m
   return 0;
 }
 
+// attention alone on random device-resident planes: ms per launch (median of rounds), nsplit 3 (split QK^T) or 1
+int zkp_bench_attention(int n_windows, int nsplit, int iters, int rounds, float* ms_out) {
+  hipStream_t s;
+  CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  const size_t rows = (size_t)n_windows * ZK_SEQ, nq = rows * 3 * ZK_HIDDEN, no = rows * ZK_HIDDEN;
+  float* f;
+  half_t *qh, *ql, *oh, *ol;
+  CK(hipMalloc((void**)&f, nq * 4)); CK(hipMalloc((void**)&qh, nq * 2)); CK(hipMalloc((void**)&ql, nq * 2));
+  CK(hipMalloc((void**)&oh, no * 2)); CK(hipMalloc((void**)&ol, no * 2));
+  hipLaunchKernelGGL(fill_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, f, (int64_t)nq, 7u, 1.0f);
+  zk_launch_split_f32(f, (int64_t)nq, 1.f, qh, ql, s);
+  CK(hipStreamSynchronize(s));
+  (void)hipFree(f);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<float> t;
+  for (int r = 0; r < rounds + 1; ++r) {
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+      zk_launch_attention(zk_planes{qh, nsplit == 3 ? ql : nullptr, ZK_LO_F16, nullptr}, zk_planes{oh, ol, ZK_LO_C8, nullptr}, n_windows, nsplit, 0, s);
+    CK(hipEventRecord(e1, s));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) t.push_back(ms / iters);
+  }
+  CK(hipGetLastError());
+  std::sort(t.begin(), t.end());
+  *ms_out = t[t.size() / 2];
+  (void)hipFree(qh); (void)hipFree(ql); (void)hipFree(oh); (void)hipFree(ol);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+  return 0;
+}
+
 }  // extern "C"

@@ -39,6 +39,9 @@ def init_comm(ctx, rank: int, world: int, exchange=None) -> None:
     if world == 1:
         ctx.comm_init(0, 1, None)
         return
+    import os
+    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # one node: bootstrap over loopback (the host name may not resolve)
     uid = lib.comm_unique_id() if rank == 0 else None
     if exchange is None:
         def exchange(payload):
