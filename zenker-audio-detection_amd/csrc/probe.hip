@@ -104,8 +104,10 @@ int zkp_bench_gemm_c8(int M, int N, int K, int epi, int variants, int iters, int
   CK(hipMalloc((void**)&fx, nx * 4)); CK(hipMalloc((void**)&fw, nw * 4)); CK(hipMalloc((void**)&bias, (size_t)N * 4));
   CK(hipMalloc((void**)&xh, nx * 2)); CK(hipMalloc((void**)&xl, nx * 2));
   CK(hipMalloc((void**)&wh, nw * 2)); CK(hipMalloc((void**)&wl, nw * 2));
-  hipLaunchKernelGGL(fill_kernel, dim3((nx + 255) / 256), dim3(256), 0, s, fx, (int64_t)nx, 1u, 1.0f);
-  hipLaunchKernelGGL(fill_kernel, dim3((nw + 255) / 256), dim3(256), 0, s, fw, (int64_t)nw, 2u, 0.05f);
+  // ZKP_ZERO=1: all-zero operands (the DVFS check of MI355X_MICROARCH.md "give-back": same cycles, higher clock)
+  const float zx = getenv("ZKP_ZERO") ? 0.0f : 1.0f;
+  hipLaunchKernelGGL(fill_kernel, dim3((nx + 255) / 256), dim3(256), 0, s, fx, (int64_t)nx, 1u, 1.0f * zx);
+  hipLaunchKernelGGL(fill_kernel, dim3((nw + 255) / 256), dim3(256), 0, s, fw, (int64_t)nw, 2u, 0.05f * zx);
   hipLaunchKernelGGL(fill_kernel, dim3((N + 255) / 256), dim3(256), 0, s, bias, (int64_t)N, 3u, 0.1f);
   const int w_exp = c8_exp(0.05f * 3.45f);
   zk_launch_split_f32(fx, (int64_t)nx, 1.f, xh, nullptr, s);
