@@ -304,3 +304,24 @@ def test_wav_decode_matches_host_reader(ctx, tmp_path):
     mono = (pcm.astype(np.float32) / 32768.0).mean(axis=1, dtype=np.float32)
     ref = orc.resample_sinc_hann(mono, 48000, 16000)
     assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-6
+
+
+def test_wav_source_slices_are_the_whole_recording_bit_for_bit(ctx):
+    """zkast.dist.WavSource (what a rank of the sharded cascade uses): a slice of the FILE BYTES decoded and resampled
+    on the device gives exactly the samples the whole-recording load gives there — 48 kHz -> 16 kHz (period 3) and
+    44.1 kHz -> 16 kHz (period 441), stereo, slices at the start, in the middle and at the end."""
+    from zkast import dist as zdist, synth
+    for sr in (48000, 44100):
+        n = sr * 7 + 123
+        x = synth.synth_recording(21, n)
+        st = np.stack([x, 0.25 * x[::-1]], 1)
+        pcm = np.round(np.clip(st, -1, 1 - 1 / 32768) * 32768).astype("<i2")
+        src = zdist.WavSource(pcm.tobytes(), 1, 16, 2, sr)
+        assert ctx.audio_load(pcm.tobytes(), 1, 16, 2, sr, 16000) == src.n_samples
+        full = ctx.audio_get()
+        assert full.shape == (src.n_samples,)
+        for a0, a1 in [(0, 16000), (8000, 40000), (src.n_samples - 20000, src.n_samples), (31999, 32001), (0, src.n_samples)]:
+            off, nbytes = src.load(ctx, a0, a1)
+            part = ctx.audio_get()
+            assert nbytes <= len(src.raw) and np.array_equal(part[off: off + (a1 - a0)], full[a0:a1]), (sr, a0, a1)
+        assert src.load(ctx, 8000, 24000)[1] < len(src.raw) // 3          # a slice uploads a slice

@@ -117,11 +117,45 @@ def sharded_cascade(n_windows: int, stage_logits: Callable[[int, np.ndarray], np
     return s1, idx, s2
 
 
+class WavSource:
+    """A recording that is still file bytes (RIFF data chunk + format): a rank decodes and resamples ON THE DEVICE only
+    the frames its windows need (BASELINE configs[3]: a 30-min 48 kHz file is 173 MB of PCM16, of which a rank of 8
+    uploads an eighth).  Slices start on a multiple of the resampler's input period, so an output sample of a slice is
+    the same float as in the whole-recording result; a margin wider than the sinc kernel keeps every tap inside."""
+
+    def __init__(self, raw: bytes, format_tag: int, bits: int, channels: int, sr: int, target_sr: int = 16000):
+        self.raw, self.tag, self.bits, self.ch, self.sr, self.target = raw, format_tag, bits, channels, sr, target_sr
+        self.frame_bytes = channels * (bits // 8)
+        self.n_frames = len(raw) // self.frame_bytes
+        g = int(np.gcd(sr, target_sr))
+        self.orig, self.neu = sr // g, target_sr // g
+        self.n_samples = (self.neu * self.n_frames + self.orig - 1) // self.orig if sr != target_sr else self.n_frames
+        width = int(np.ceil(6.0 * self.orig / (min(self.orig, self.neu) * 0.99)))
+        self.margin = max(2, (width + self.orig) // self.orig + 1)      # in blocks of `orig` input frames
+
+    @classmethod
+    def from_file(cls, path: str, target_sr: int = 16000):
+        from .pipeline import parse_wav
+        tag, ch, sr, bits, raw = parse_wav(path)
+        return cls(raw, tag, bits, ch, sr, target_sr)
+
+    def load(self, ctx, a0: int, a1: int):
+        """leave output samples covering [a0, a1) in the context's audio slot; returns (offset of a0 in the slot, bytes
+        uploaded)"""
+        q0 = max(0, a0 // self.neu - self.margin)
+        q1 = -(-a1 // self.neu) + self.margin
+        f0, f1 = q0 * self.orig, min(self.n_frames, q1 * self.orig)
+        piece = self.raw[f0 * self.frame_bytes: f1 * self.frame_bytes]
+        ctx.audio_load(piece, self.tag, self.bits, self.ch, self.sr, self.target)
+        return a0 - q0 * self.neu, len(piece)
+
+
 class ZkShardedCascade:
     """Binds sharded_cascade to the HIP path for one recording.  A rank uploads and log-mels only the audio its windows
     need: `audio[lo*hop : (hi-1)*hop + win]` for its stage-1 range [lo, hi) (adjacent ranks overlap by
     win - hop samples), and, when its share of the re-partitioned gated windows leaves that range, the slice that
-    covers the share.  The logit gathers run through `zk_allgather_logits` when the context has a communicator
+    covers the share.  `audio` is a 16 kHz float array or a `WavSource` (file bytes: decoded and resampled on the
+    device, slice by slice).  The logit gathers run through `zk_allgather_logits` when the context has a communicator
     (`init_comm`), else through `torch.distributed`."""
 
     def __init__(self, model_s1, fx_s1, model_s2, fx_s2, rank: int, world: int, device=None, use_ctx_comm=None):
@@ -132,12 +166,17 @@ class ZkShardedCascade:
         if use_ctx_comm is None:
             use_ctx_comm = ctx.comm_info()[1] == world and world > 1
         self.comm_ctx = ctx if use_ctx_comm else None
-        self.h2d_samples = 0          # audio samples uploaded by the last call (what config 4 counts per rank)
+        self.h2d_samples = 0          # audio samples (array) or bytes (WavSource) uploaded by the last call
+        self.n_windows = 0
 
-    def __call__(self, audio: np.ndarray, window_sec=1.0, hop_sec=0.5, thr1=0.5, fwd_min_prob=None):
+    def __call__(self, audio, window_sec=1.0, hop_sec=0.5, thr1=0.5, fwd_min_prob=None):
         from .pipeline import window_geometry
-        audio = np.ascontiguousarray(audio, dtype=np.float32)
-        n, win, hop = window_geometry(len(audio), window_sec, hop_sec)
+        src = audio if isinstance(audio, WavSource) else None
+        if src is None:
+            audio = np.ascontiguousarray(audio, dtype=np.float32)
+        n_samples = src.n_samples if src is not None else len(audio)
+        n, win, hop = window_geometry(n_samples, window_sec, hop_sec)
+        self.n_windows = n
         ctx = self.m[0]._ctx
         for m, fx in zip(self.m, self.fx):
             m.bind_feature_extractor(fx)
@@ -148,10 +187,15 @@ class ZkShardedCascade:
             if lo >= slot[0] and hi <= slot[1]:
                 return
             a0 = lo * hop
-            a1 = min(len(audio), (hi - 1) * hop + win)      # a recording shorter than one window is zero-padded
-            piece = audio[a0:a1]
-            ctx.logmel(piece, len(piece), 0, hop, win, hi - lo)
-            self.h2d_samples += len(piece)
+            a1 = min(n_samples, (hi - 1) * hop + win)      # a recording shorter than one window is zero-padded
+            if src is not None:
+                off, nbytes = src.load(ctx, a0, a1)
+                ctx.logmel(None, 0, off, hop, win, hi - lo)
+                self.h2d_samples += nbytes
+            else:
+                piece = audio[a0:a1]
+                ctx.logmel(piece, len(piece), 0, hop, win, hi - lo)
+                self.h2d_samples += len(piece)
             slot[0], slot[1] = lo, hi
 
         def stage_logits(stage, win_idx):
