@@ -8,7 +8,7 @@ lib.zkp_fill_probe.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_float)]
 M = (int(sys.argv[1]) if len(sys.argv) > 1 else 512) * 1214
 for name, N, K in [("qkv", 2304, 768), ("fc1", 3072, 768), ("o", 768, 768), ("fc2", 768, 3072)]:
     for depth in (1, 2):
-        for fix in (0, 1, 2, 3):
+        for fix in (0, 1, 2, 3, 4):
             ms = C.c_float()
             rc = lib.zkp_fill_probe(M, N, K, depth, fix, 3, C.byref(ms))
             if rc:

@@ -63,9 +63,11 @@ __global__ __launch_bounds__(512) void fill_probe_kernel(const half_t* x_hi, con
         const char* xb = (const char*)(xp + (size_t)m0 * K + k * 64);
         const char* wb = (const char*)(wp + (size_t)n0 * K + k * 64);
         char* base = smem + slot * 65536;
+        // fix & 4: the X plane as [row block][k step][256 rows][128 B] tiles -> a step's X is 32 KiB CONTIGUOUS
+        const char* xt = (const char*)xp + ((size_t)(m0 / 256) * nk + k) * 32768;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + poffs[q]),
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((fix & 4) ? xt + (q * 8 + wave) * 1024 + lane * 16 : xb + poffs[q]),
                                            (__attribute__((address_space(3))) void*)(base + (q * 8 + wave) * 1024), 16, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
