@@ -35,9 +35,20 @@ def _worker(rank, world, port, q):
     (m1, fx1), (m2, fx2) = _models()
     rec = synth.synth_recording(3, 16000 + 15 * 8000)
     s1, idx, s2 = zdist.ZkShardedCascade(m1, fx1, m2, fx2, rank, world)(rec, 1.0, 0.5, 0.5)
-    q.put((rank, s1, idx, s2))
+    # the same recording as 48 kHz stereo FILE BYTES: every rank decodes + resamples only its slices on the device
+    casc = zdist.ZkShardedCascade(m1, fx1, m2, fx2, rank, world)
+    w1, widx, w2 = casc(_wav_source(), 1.0, 0.5, 0.5)
+    q.put((rank, s1, idx, s2, w1, widx, w2, casc.h2d_samples))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _wav_source():
+    from zkast import dist as zdist
+    from zkast import synth
+    x = synth.synth_recording(5, 48000 * 9 + 77)
+    pcm = np.round(np.clip(np.stack([x, 0.5 * x], 1), -1, 1 - 1 / 32768) * 32768).astype("<i2")
+    return zdist.WavSource(pcm.tobytes(), 1, 16, 2, 48000)
 
 
 def test_two_rank_sharded_cascade_matches_single_process():
@@ -47,6 +58,9 @@ def test_two_rank_sharded_cascade_matches_single_process():
     rec = synth.synth_recording(3, 16000 + 15 * 8000)
     ref1, refi, ref2 = zdist.ZkShardedCascade(m1, fx1, m2, fx2, 0, 1)(rec, 1.0, 0.5, 0.5)
     assert 0 < len(refi) < 16
+    src = _wav_source()
+    wref1, wrefi, wref2 = zdist.ZkShardedCascade(m1, fx1, m2, fx2, 0, 1)(src, 1.0, 0.5, 0.5)
+    assert wref1.shape == (17, 2)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -57,9 +71,12 @@ def test_two_rank_sharded_cascade_matches_single_process():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    for rank, s1, idx, s2 in res:
+    for rank, s1, idx, s2, w1, widx, w2, h2d in res:
         # per-window arithmetic does not depend on which windows share a micro-batch -> bit-identical
         assert np.array_equal(s1, ref1) and np.array_equal(idx, refi) and np.array_equal(s2, ref2)
+        # ... nor on whether the window's samples were decoded from a slice of the file or from the whole file
+        assert np.array_equal(w1, wref1) and np.array_equal(widx, wrefi) and np.array_equal(w2, wref2)
+        assert h2d < 2 * len(src.raw)
 
 
 def test_rccl_allgather_through_the_c_abi_world_of_one():
