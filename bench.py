@@ -92,6 +92,11 @@ def main():
             print(f"[bench] rank {rank}: RCCL communicator failed ({e}); falling back to a host gather over gloo", file=sys.stderr)
             collective = "FALLBACK: host all-gather over gloo (RCCL communicator could not be created)"
     use_rccl = world > 1 and ctx.comm_info()[1] == world
+    if world > 1:      # all ranks take the same path: one failed communicator sends everyone to the fallback
+        import torch as _t
+        ok = _t.tensor([1 if use_rccl else 0])
+        tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)
+        use_rccl = bool(ok.item())
 
     S1 = (-1.1509622, 3.5340312)
     S2 = (-6.5, 2.75)
