@@ -5,7 +5,7 @@ lib = C.CDLL(os.environ.get("ZKAST_PROBES", os.path.join(ROOT, "zenker-audio-det
 lib.zkp_bench_attention.restype = C.c_int
 lib.zkp_bench_attention.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_float)]
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-for ns in (3, 1):
+for ns in (3, 2, 1):
     ms = C.c_float()
     rc = lib.zkp_bench_attention(W, ns, 3, 5, C.byref(ms))
     fl = W * 12 * 4.0 * 1214 * 1214 * 64

@@ -12,7 +12,28 @@ def fp8(x, kind="e4m3"):
         return t.clamp(-448, 448).to(torch.float8_e4m3fn).float().numpy()
     return t.clamp(-57344, 57344).to(torch.float8_e5m2).float().numpy()
 
+def e2m3(x):
+    """round-to-nearest-even onto the OCP fp6 e2m3 grid (max 7.5, subnormal step 0.125), saturating"""
+    a = np.minimum(np.abs(x), 7.5)
+    e = np.floor(np.log2(np.maximum(a, 1.0)))              # 0, 1, 2 for normals; subnormals use the step of e = 0
+    step = np.exp2(e - 3.0)
+    return np.sign(x) * np.minimum(np.round(a / step) * step, 7.5)      # np.round = half to even
+
+
+def mx6_blocks(lo, val, blk=16):
+    """MX-fp6 planes of a [rows, K] operand pair: one power-of-two scale per (row, blk k-elements) shared by the `lo`
+    and the `val` entries of the block (32 values), chosen so that the block maximum lands in (3.75, 7.5]"""
+    r, k = val.shape
+    v = val.reshape(r, k // blk, blk); l = lo.reshape(r, k // blk, blk)
+    amax = np.maximum(np.abs(v).max(-1), np.abs(l).max(-1))
+    s = np.where(amax > 0, np.ceil(np.log2(np.maximum(amax, 1e-38) / 7.5)), 0.0)[..., None]
+    sc = np.exp2(s).astype(np.float32)
+    return (e2m3(l / sc) * sc).reshape(r, k).astype(np.float32), (e2m3(v / sc) * sc).reshape(r, k).astype(np.float32)
+
+
 SCHEME = "x3"
+import os
+QK = os.environ.get("QK", "x3")      # attention score product: x3 (3 fp16 passes) | c8 | f16
 STAT = {}
 def lin(x, w, b, quant):
     x = np.asarray(x, np.float32); w = np.asarray(w, np.float32)
@@ -35,6 +56,14 @@ def lin(x, w, b, quant):
         STAT["xsat"] = max(STAT.get("xsat", 0), float(np.abs(x * 2.0**c).max()))
         corr = (xl8 @ w8.T + x8 @ wl8.T) * np.float32(2.0 ** -(a + d))
         return xh @ wh.T + corr + b
+    if SCHEME.startswith("fp6"):
+        # block-scaled e2m3 correction planes: X' = (Xl*2^11, X), W' = (W, Wl*2^11) with per-(row, 16 k) scales
+        blk = 32 if "b32" in SCHEME else 16
+        x2 = x.reshape(-1, x.shape[-1])
+        xl6, x6 = mx6_blocks((x2 - xh.reshape(x2.shape)) * 2048.0, x2, blk)
+        wl6, w6 = mx6_blocks((w - wh) * 2048.0, w, blk)
+        corr = ((xl6 @ w6.T + x6 @ wl6.T) * np.float32(2.0 ** -11)).reshape(x.shape[:-1] + (w.shape[0],))
+        return xh @ wh.T + corr + b
     raise ValueError
 def qk_pv_layer(h, L, quant=None):
     # device arithmetic for attention: split QK^T (3 terms), single-pass f16 P.V
@@ -46,7 +75,14 @@ def qk_pv_layer(h, L, quant=None):
         s = q @ k.transpose(0, 1, 3, 2)
     else:
         qh, kh = f16(q), f16(k); ql, kl = f16(q - qh), f16(k - kh)
-        s = qh @ kh.transpose(0, 1, 3, 2) + (ql @ kh.transpose(0, 1, 3, 2) + qh @ kl.transpose(0, 1, 3, 2))
+        if QK == "c8":      # fp16 main product + ONE fp8 pass over byte pairs (fp8(ql 2^11), fp8(q)) x (fp8(k), fp8(kl 2^11))
+            kt = lambda t: t.transpose(0, 1, 3, 2)
+            STAT["kmax"] = max(STAT.get("kmax", 0), float(np.abs(k).max()))
+            s = qh @ kt(kh) + (fp8((q - qh) * 2048.0) @ kt(fp8(k)) + fp8(q) @ kt(fp8((k - kh) * 2048.0))) * np.float32(2.0 ** -11)
+        elif QK == "f16":
+            s = qh @ kh.transpose(0, 1, 3, 2)
+        else:
+            s = qh @ kh.transpose(0, 1, 3, 2) + (ql @ kh.transpose(0, 1, 3, 2) + qh @ kl.transpose(0, 1, 3, 2))
     s = s - s.max(-1, keepdims=True); e = np.exp(s)
     if SCHEME == "f32":
         a = (e / e.sum(-1, keepdims=True)) @ v
@@ -72,5 +108,5 @@ def main():
         SCHEME = s; STAT.clear()
         orc._lin = (lambda x, w, b, q: real_lin(x, w, b, None)) if s == "f32" else lin
         t = time.time(); out = orc.ast_forward(feats, sd)
-        print(f"{s:12s} max|dlogit| = {np.abs(out - ref).max():.3e}  rms {np.sqrt(((out-ref)**2).mean()):.3e}  xmax {STAT.get('xsat',0):.1f}  ({time.time()-t:.0f}s)", flush=True)
+        print(f"{s:12s} max|dlogit| = {np.abs(out - ref).max():.3e}  rms {np.sqrt(((out-ref)**2).mean()):.3e}  xmax {STAT.get('xsat',0):.1f} kmax {STAT.get('kmax',0):.1f}  ({time.time()-t:.0f}s)", flush=True)
 main()

@@ -13,12 +13,40 @@
 //  * K/V tiles are prefetched global->VGPR during the MFMA phase and written to the other LDS buffer after it.
 //  * NSPLIT=3: q and k are (hi, lo) fp16 pairs, Sᵀ += Kh·Qh + Kl·Qh + Kh·Ql (the scores feed exp(), which
 //    amplifies operand rounding); P·V stays single-pass (measured contribution 8e-5 on the logits).
+//  * NSPLIT=2 (ZK_F16C8): the two correction products ride ONE fp8 pass as in gemm_c8.hip: k's lo plane holds the c8
+//    byte pairs (fp8(kl·2^11), fp8(k)) written by the QKV epilogue, the kernel builds q' = (fp8(q), fp8(ql·2^11)) once
+//    in registers, and Sᵀ += Kh·Qh (4 x 32x32x16 fp16) + K'·Q'·2^-11 (2 x v_mfma_scale_f32_32x32x64_f8f6f4) per 32
+//    keys: 256 matrix-pipe cycles instead of 384.  The byte order inside a lane's 32 K'-bytes is the order of the
+//    lane's fp16 fragments (d = 16ks + 8·half + j), so the c8 fragment reads use the Kh addresses in the next image.
 //  * softmax in the log2 domain (v_exp_f32): the scale is folded into q, the negated running max is the C operand of
 //    the score MFMAs (no per-score subtract), O/l are rescaled only when the max moves by more than 2^8 (deferred
 //    rescale); fp32 running max / sum, keys >= 1214 of the last tile masked.
+#include <type_traits>
+#include <utility>
+
 #include "zk_common.h"
 
 namespace {
+
+#ifndef ZK_ATT_DMA_TOP
+#define ZK_ATT_DMA_TOP 0      // 1: all staging pieces at the top of the iteration instead of between the MFMA slots
+#endif
+#ifndef ZK_ATT_ABL
+#define ZK_ATT_ABL 0      // probe builds only: 1 no K/V staging, 2 no barrier, 4 no exponentials
+#endif
+typedef int i2v_t __attribute__((ext_vector_type(2)));
+typedef int i4v_t __attribute__((ext_vector_type(4)));
+typedef int i8v_t __attribute__((ext_vector_type(8)));
+
+// compile-time loop: f(integral_constant<int, I>) for I in [0, N)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 constexpr int S_ = ZK_SEQ;
 constexpr int QKV_LD = 3 * ZK_HIDDEN;   // 2304
@@ -32,9 +60,9 @@ template <int NSPLIT>
 __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict__ qkv_hi,
                                                         const half_t* __restrict__ qkv_lo, half_t* __restrict__ o_hi,
                                                         half_t* __restrict__ o_lo, int n_windows, int q_tiles, int lo_fmt) {
-  constexpr bool SPLIT = (NSPLIT == 3);
-  constexpr int NIMG = SPLIT ? 3 : 2;     // Kh, [Kl], V
-  constexpr int BUF_B = NIMG * TILE_B;
+  constexpr bool SPLIT = (NSPLIT >= 2);
+  constexpr bool C8 = (NSPLIT == 2);
+  constexpr int NIMG = SPLIT ? 3 : 2;     // Kh, [Kl | Kc8], V
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -59,7 +87,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   // ---- Q fragments (B operand: lane holds Q[q = lane&31][d = 16ks + 8*half + j]) ----
   const int q_row = qt * QT + wave * 32 + (lane & 31);
   const int q_ld = q_row < S_ ? q_row : S_ - 1;
-  h8_t qh[4], ql[SPLIT ? 4 : 1];
+  h8_t qh[4], ql[(SPLIT && !C8) ? 4 : 1];
+  i8v_t qc[C8 ? 2 : 1];      // C8: q' for the two 64-byte-deep fp8 MFMAs (ks = 2t, 2t+1)
   {
     const size_t off = (tok0 + q_ld) * QKV_LD + head * ZK_HEAD_DIM + 8 * half;
 #pragma unroll
@@ -73,65 +102,68 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
         if constexpr (SPLIT) qf += (float)ql[ks][e];
         qf *= 0.125f * 1.4426950408889634f;
         qh[ks][e] = (half_t)qf;
-        if constexpr (SPLIT) ql[ks][e] = (half_t)(qf - (float)qh[ks][e]);
+        if constexpr (SPLIT && !C8) ql[ks][e] = (half_t)(qf - (float)qh[ks][e]);
+        if constexpr (C8) {
+          const int di = (ks & 1) * 4 + (e >> 1);
+          const float l11 = zk_clamp_fp8((qf - (float)qh[ks][e]) * 2048.f);
+          qc[ks >> 1][di] = (e & 1) ? __builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8(qf), l11, qc[ks >> 1][di], true)
+                                    : __builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8(qf), l11, 0, false);
+        }
       }
     }
   }
 
-  // ---- K/V staging (global -> VGPR -> LDS) ----
-  // 512 16-B chunks per image; thread handles chunks tid and tid+256: row = c>>3, col chunk = c&7
-  h8_t pk[NIMG][2];
-  // per-lane byte offsets of this thread's two 16-B chunks inside a 64-key tile, computed once (the last tile clamps
-  // keys >= 1214 to 1213): a tile load is then 6 x global_load_dwordx4 v, v_off, s[base] with no vector address math
-  unsigned toff[2];
-  auto set_offs = [&](int kt) {
+  // ---- K/V staging: LDS-DMA (global_load_lds_dwordx4) into 3-deep rings ----
+  // The loop is software-pipelined by one tile: iteration t multiplies K(t+1)·Qᵀ BESIDE the softmax of tile t (the
+  // matrix pipe holds the SIMD's issue for 8 of an MFMA's 32 cycles, the exp / max / cvt stream of the previous tile
+  // fills the other 24), then V(t)ᵀ·Pᵀ.  So K runs one tile ahead of V.  Iteration t issues the DMA of K(t+3) and
+  // V(t+2) into the ring slots that K(t) / V(t-1) left at the previous barrier and ends on vmcnt(PER_ITER): everything
+  // but its own pieces has landed, i.e. a piece has a whole iteration (~1 us) to arrive, costs no VGPR and no ds_write.
+  // A piece = one wave instruction = 8 rows x 128 B (1 KiB) of one image, lane -> (row = lane>>3, 16-B LDS chunk =
+  // lane&7); the XOR swizzles of the images are applied on the SOURCE side (the DMA writes LDS lane-linearly).
+  // A 64-key image has 8 pieces: wave w issues pieces w and w+4 (rows +32: same swizzle term).
+  constexpr int NKIMG = NIMG - 1;     // K images (Kh, [Kl | Kc8])
+  constexpr int PER_ITER = 2 * NIMG;  // DMA instructions per wave and iteration
+  unsigned koff[2], voff[2], koff_last[2], voff_last[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int c = tid + u * 256;
-      const int row = c >> 3, cc = c & 7;
-      int key = kt * KT + row;
-      key = key < S_ ? key : S_ - 1;
-      toff[u] = (unsigned)(key - kt * KT) * (unsigned)(QKV_LD * 2) + (unsigned)(cc * 16);
-    }
-  };
-  set_offs(0);
+  for (int u = 0; u < 2; ++u) {
+    const int row = (wave + 4 * u) * 8 + (lane >> 3), cl = lane & 7;
+    const unsigned kc = (unsigned)((cl ^ ((row >> 1) & 7)) << 4), vc = (unsigned)((cl ^ (((row >> 1) & 1) << 2)) << 4);
+    koff[u] = (unsigned)row * (unsigned)(QKV_LD * 2) + kc;
+    voff[u] = (unsigned)row * (unsigned)(QKV_LD * 2) + vc;
+    int key = (NKT - 1) * KT + row;      // last tile: keys >= 1214 (masked later) re-read key 1213
+    key = key < S_ ? key : S_ - 1;
+    const unsigned rl = (unsigned)(key - (NKT - 1) * KT) * (unsigned)(QKV_LD * 2);
+    koff_last[u] = rl + kc;
+    voff_last[u] = rl + vc;
+  }
   auto uniform_ptr = [](const char* p) {
     const unsigned long long g = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)g);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
     return (const char*)(((unsigned long long)hi << 32) | lo);
   };
-  // The loads name the GLOBAL address space: a pointer rebuilt from readfirstlane'd integers is otherwise generic and
-  // hipcc emits flat_load, which also counts in lgkmcnt — every wait for a K/V fragment read of the CURRENT tile then
-  // waits for the HBM round trip of the NEXT tile's prefetch.
-  typedef __attribute__((address_space(1))) h8_t GLOBAL_H8;
-  auto load_tile = [&](int kt) {
-    if (kt == NKT - 1) set_offs(kt);
-    const size_t tb = ((tok0 + (size_t)kt * KT) * QKV_LD + head * ZK_HEAD_DIM) * 2;     // bytes
-    const char* gk = uniform_ptr((const char*)qkv_hi + tb + ZK_HIDDEN * 2);
-    const char* gv = uniform_ptr((const char*)qkv_hi + tb + 2 * ZK_HIDDEN * 2);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      pk[0][u] = *(const GLOBAL_H8*)(gk + toff[u]);
-      if constexpr (SPLIT) {
-        const char* gl = uniform_ptr((const char*)qkv_lo + tb + ZK_HIDDEN * 2);
-        pk[1][u] = *(const GLOBAL_H8*)(gl + toff[u]);
-      }
-      pk[NIMG - 1][u] = *(const GLOBAL_H8*)(gv + toff[u]);
-    }
+  // LDS: K ring = 3 x NKIMG images at 0, V ring = 3 images behind it
+  constexpr int KBUF_B = NKIMG * TILE_B;
+  constexpr int V_OFF = 3 * KBUF_B;
+  auto dma = [&](const char* gbase, unsigned off, char* lds) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + off),
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
   };
-  auto store_tile = [&](int buf) {
-    char* base = smem + buf * BUF_B;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int c = tid + u * 256;
-      const int row = c >> 3, cc = c & 7;
-      const int kofs = row * 128 + ((cc ^ ((row >> 1) & 7)) << 4);
-      *(h8_t*)(base + kofs) = pk[0][u];
-      if constexpr (SPLIT) *(h8_t*)(base + TILE_B + kofs) = pk[1][u];
-      const int vofs = row * 128 + ((cc ^ (((row >> 1) & 1) << 2)) << 4);
-      *(h8_t*)(base + (NIMG - 1) * TILE_B + vofs) = pk[NIMG - 1][u];
-    }
+  // piece pc (0 .. PER_ITER-1) of the iteration's staging: K images of tile kt_k -> K slot sk (pieces 0 .. 2·NKIMG-1),
+  // V image of tile kt_v -> V slot sv.  Tiles are clamped to the last one: the surplus fetches of the final iterations
+  // land in dead slots.
+  auto dma_piece = [&](int pc, int kt_k, int sk, int kt_v, int sv) __attribute__((always_inline)) {
+    const bool isk = pc < 2 * NKIMG;
+    int kt = isk ? kt_k : kt_v;
+    kt = kt < NKT - 1 ? kt : NKT - 1;
+    const bool last = kt == NKT - 1;
+    const int u = pc & 1, img = isk ? pc >> 1 : 0;
+    const size_t tb = ((tok0 + (size_t)kt * KT) * QKV_LD + head * ZK_HEAD_DIM) * 2;     // bytes
+    const char* src = (img == 1 ? (const char*)qkv_lo : (const char*)qkv_hi) + tb + (isk ? 1 : 2) * ZK_HIDDEN * 2;
+    char* base = isk ? smem + sk * KBUF_B + img * TILE_B : smem + V_OFF + sv * TILE_B;
+    const unsigned o = isk ? (last ? koff_last[u] : koff[u]) : (last ? voff_last[u] : voff[u]);
+    dma(uniform_ptr(src), o, base + (wave + 4 * u) * 1024);
   };
 
   // ---- per-lane LDS read offsets ----
@@ -150,105 +182,269 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   // running max m_run (log2 domain) is kept NEGATED in a 16-register vector that is the C operand of each score
   // block's first MFMA: the accumulator then holds s - m_run directly and exp2 needs no subtraction.  m_run only
   // moves when some row's block maximum exceeds it by more than RESCALE_THR (p <= 2^8 is harmless in fp16/fp32);
-  // that rare path rescales O and l (T13-style deferred rescale, wave-uniform branch).
+  // that rare path rescales O and l — and the scores of the NEXT tile, which were started with the old maximum
+  // (T13-style deferred rescale, wave-uniform branch).
   constexpr float RESCALE_THR = 8.0f;
   f16_t negm;
 #pragma unroll
   for (int i = 0; i < 16; ++i) negm[i] = 0.f;
   float m_run = 0.f, l_run = 0.f;
 
+  // ---- one key tile as a sequence of SLOTS ----
+  // A slot = the LDS fragment reads of the slot two ahead, one group of MFMAs, and a share of the VALU work, fenced by
+  // sched_barrier so that hipcc keeps the interleave (left alone it runs the MFMAs back to back, each behind its own
+  // LDS round trip, and the softmax after them).
+  //   score slots (tile t+1):  C8: per 32-key block 2 fp8 groups (1 MFMA, 64 cycles, 4 exps) + 4 fp16 groups (1 MFMA,
+  //                            32 cycles, 2 exps); X3: 8 groups of 3 MFMAs, 4 exps; F16: 8 groups of 1 MFMA, 4 exps
+  //   PV slots (tile t):       8 groups of 1 MFMA + 4 elements of the next tile's row maximum
+  struct kf_t { i4v_t a, b; };
+  constexpr int NG_QK = C8 ? 12 : 8;
+  constexpr int NSLOT = NG_QK + 8;
+#ifndef ZK_ATT_LA
+#define ZK_ATT_LA 4
+#endif
+  constexpr int LA = ZK_ATT_LA;      // fragment reads run this many slots ahead (LA + 1 fragment register sets)
+  kf_t fr[LA + 1];
+  // Fragment reads are inline asm with hand-counted s_waitcnt lgkmcnt: hipcc cannot tell the LDS-DMA pieces of the ring
+  // from the fragment reads and would put vmcnt(0) between them, and its own lgkmcnt placement drains the lookahead.
+  // LDS reads retire in order, so the fragment of group g is valid once all but the reads issued after it have
+  // returned: lgkmcnt(reads of groups g+1 .. g+LA).  Addresses are per-lane bases (+ ring slot, once per iteration)
+  // plus immediates.
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  unsigned kofs[4], vofs[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kofs[ks] = lds0 + (unsigned)(kfrag_row + (((2 * ks + half) ^ kfrag_sw) << 4));
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+    vofs[mb] = lds0 + (unsigned)(V_OFF + v_key * 128 + (((4 * mb + v_chunk) ^ v_sw) << 4) + v_byte);
+  unsigned ka[4], va[2];      // the same with the ring slots of the iteration added
+  auto nreads = [](int g) constexpr { return g >= NG_QK ? 2 : (C8 ? ((g % 6) < 2 ? 2 : 1) : (SPLIT ? 2 : 1)); };
+  auto reads_after = [nreads](int g) constexpr {
+    int n = 0;
+    for (int j = g + 1; j <= g + LA && j < NSLOT; ++j) n += nreads(j);
+    return n;
+  };
+  auto load_group = [&](auto gc) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    kf_t& f = fr[g % (LA + 1)];
+    if constexpr (g < NG_QK) {
+      if constexpr (C8) {
+        constexpr int kb = g / 6, i = g % 6;
+        if constexpr (i < 2) {      // c8 image, chunks of ks = 2i and 2i+1
+          asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
+                       : "=&v"(f.a), "=&v"(f.b) : "v"(ka[2 * i]), "v"(ka[2 * i + 1]), "n"(kb * 4096 + TILE_B));
+        } else {
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a) : "v"(ka[i - 2]), "n"(kb * 4096));
+        }
+      } else {
+        constexpr int kb = g / 4, ks = g % 4;
+        if constexpr (SPLIT)
+          asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                       : "=&v"(f.a), "=&v"(f.b) : "v"(ka[ks]), "n"(kb * 4096), "n"(kb * 4096 + TILE_B));
+        else
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a) : "v"(ka[ks]), "n"(kb * 4096));
+      }
+    } else {
+      constexpr int v = g - NG_QK, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
+      i2v_t t0, t1;
+      asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                   : "=&v"(t0), "=&v"(t1) : "v"(va[mb]), "n"((kb * 32 + 16 * sx) * 128), "n"((kb * 32 + 16 * sx + 8) * 128));
+      f.a = __builtin_shufflevector(t0, t1, 0, 1, 2, 3);
+    }
+  };
+  // the fragment of group g is in its registers (see above); names them so that no MFMA moves in front of the wait
+  auto wait_group = [&](auto gc, auto n_c) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    kf_t& f = fr[g % (LA + 1)];
+    if constexpr (nreads(g) == 2 && g < NG_QK)
+      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.a), "+v"(f.b) : "n"(decltype(n_c)::value));
+    else
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f.a) : "n"(decltype(n_c)::value));
+  };
+  // the MFMAs of score group g into sn (scores of the next tile minus the running max)
+  auto mma_group = [&](auto gc, f16_t (&sn)[2]) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    const kf_t& f = fr[g % (LA + 1)];
+    if constexpr (C8) {
+      constexpr int kb = g / 6, i = g % 6;
+      if constexpr (i < 2) {
+        const i8v_t kc = __builtin_shufflevector(f.a, f.b, 0, 1, 2, 3, 4, 5, 6, 7);
+        sn[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kc, qc[i], i == 0 ? negm : sn[kb], 0, 0, 0,
+                                                                 127 - ZK_C8_SHIFT, 0, 127);
+      } else {
+        sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, f.a), qh[i - 2], sn[kb], 0, 0, 0);
+      }
+    } else {
+      constexpr int kb = g / 4, ks = g % 4;
+      const h8_t kh = __builtin_bit_cast(h8_t, f.a);
+      if constexpr (SPLIT) {
+        const h8_t kl = __builtin_bit_cast(h8_t, f.b);
+        sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], ks == 0 ? negm : sn[kb], 0, 0, 0);
+        sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sn[kb], 0, 0, 0);
+        sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sn[kb], 0, 0, 0);
+      } else {
+        sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], ks == 0 ? negm : sn[kb], 0, 0, 0);
+      }
+    }
+  };
+  // first and count of the 32 exponentials that ride in score slot g
+  auto exp_first = [](int g) constexpr { return C8 ? (g / 6) * 16 + ((g % 6) < 2 ? 4 * (g % 6) : 8 + 2 * ((g % 6) - 2)) : 4 * g; };
+  auto exp_count = [](int g) constexpr { return C8 ? ((g % 6) < 2 ? 4 : 2) : 4; };
+
+  // a wave whose 32 query rows all lie beyond the sequence (the last query tile holds 62 of 128 rows: waves 2 and 3)
+  // only takes part in the K/V staging and the barriers — its SIMD time goes to the other resident workgroup
   const bool wave_active = __builtin_amdgcn_readfirstlane(qt * QT + wave * 32) < S_;
-  load_tile(0);
-  store_tile(0);
+#pragma unroll
+  for (int pc = 0; pc < PER_ITER; ++pc) {
+    dma_piece(pc, 0, 0, 0, 0);
+    dma_piece(pc, 1, 1, 1, 1);
+    if (pc < 2 * NKIMG) dma_piece(pc, 2, 2, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int kt = 0; kt < NKT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < NKT) load_tile(kt + 1);
-    const char* kb_base = smem + cur * BUF_B;
-    const char* vb_base = kb_base + (NIMG - 1) * TILE_B;
+  // row maximum of a score tile (in-lane over the 32 keys, then across the two half-waves)
+  auto row_max = [&](f16_t (&sc)[2]) __attribute__((always_inline)) {
+    float mx = fmaxf(sc[0][0], sc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sc[0][r], sc[1][r]));
+    return fmaxf(mx, __shfl_xor(mx, 32, 64));
+  };
+  // move the running max by delta: scores of the current tile, O and l follow
+  auto rescale = [&](f16_t (&sc)[2], float delta, float alpha) __attribute__((always_inline)) {
+    m_run += delta;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[0][r] -= delta; sc[1][r] -= delta; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; negm[i] = -m_run; }
+    l_run *= alpha;
+  };
 
-    // a wave whose 32 query rows all lie beyond the sequence (the last query tile holds 62 of 128 rows: waves 2 and 3)
-    // only takes part in the K/V staging and the barriers — its SIMD time goes to the other resident workgroup
+  f16_t sA[2], sB[2];
+  float mx = 0.f;
+  if (wave_active) {      // scores of tile 0 (no overlap partner yet)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[ks] = kofs[ks];      // K(0) is in slot 0
+    static_for<NG_QK>([&](auto gc) __attribute__((always_inline)) {
+      load_group(gc);
+      wait_group(gc, std::integral_constant<int, 0>{});
+      mma_group(gc, sA);
+    });
+    mx = row_max(sA);
+    rescale(sA, mx, 1.0f);      // first tile: the running max starts at its row maximum
+    mx = 0.f;
+  }
+  __syncthreads();      // K(0) has been read by every wave: iteration 0 overwrites its slot
+
+  int kslot = 0;      // ring slot of the current tile (kt % 3)
+  // One key tile.  sc: its scores minus the running max, mx: their row maximum (both from the previous iteration);
+  // sn: receives the scores of tile kt+1.  LAST: no next tile; MASKNEXT: tile kt+1 is the last one (masked keys).
+  auto iteration = [&](int kt, f16_t (&sc)[2], f16_t (&sn)[2], auto last_c, auto masknext_c) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_c)::value;
+    constexpr bool MASKNEXT = decltype(masknext_c)::value;
+    constexpr int G0 = LAST ? NG_QK : 0;      // the last tile has PV slots only
+    // ring slots: K(t) sits in slot t % 3 (ks0), V(t) in slot t % 3 (vs0)
+    const int s0 = kslot, s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;      // t%3, (t+1)%3, (t+2)%3
+    // staging of K(t+3) -> slot of K(t) (dead since the previous barrier) and V(t+2) -> slot of V(t-1) = (t+2) % 3: one
+    // piece every DMA_EVERY slots, between the MFMAs (a piece holds the issuing wave for ~100 cycles)
+    constexpr int DMA_EVERY = NSLOT / PER_ITER;
+    auto stage_piece = [&](int pc) __attribute__((always_inline)) {
+#if !(ZK_ATT_ABL & 1)
+      dma_piece(pc, kt + 3, s0, kt + 2, s2);
+#endif
+    };
+    if constexpr (!LAST) {
+      if (!wave_active || ZK_ATT_DMA_TOP) {
+#pragma unroll
+        for (int pc = 0; pc < PER_ITER; ++pc) stage_piece(pc);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[ks] = kofs[ks] + (unsigned)(s1 * KBUF_B);      // K(t+1)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) va[mb] = vofs[mb] + (unsigned)(s0 * TILE_B);       // V(t)
+
     if (wave_active) {
-    // ---- scores minus running max: two 32-key blocks ----
-    f16_t sacc[2];
+      // deferred rescale (rare, wave-uniform): before the next tile's scores are started with the running max
+      if (!__all(mx <= RESCALE_THR)) {
+        const float delta = fmaxf(mx, 0.f);
+        rescale(sc, delta, __builtin_amdgcn_exp2f(-delta));
+      }
+      float psum = 0.f, mxp = -3.0e38f;
+      h8_t pf[2][2];
+      static_for<LA>([&](auto gc) __attribute__((always_inline)) {
+        load_group(std::integral_constant<int, G0 + decltype(gc)::value>{});
+      });
+      if constexpr (LAST) {      // nothing to overlap the exponentials with
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+        for (int e = 0; e < 32; ++e) {
+          const float p = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15]);
+          psum += p;
+          pf[e >> 4][(e & 15) >> 3][e & 7] = (half_t)p;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<NSLOT - G0>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int g = G0 + decltype(ic)::value;
+        if constexpr (!ZK_ATT_DMA_TOP && !LAST && g % DMA_EVERY == DMA_EVERY - 1 && g / DMA_EVERY < PER_ITER) stage_piece(g / DMA_EVERY);
+        if constexpr (g + LA < NSLOT) load_group(std::integral_constant<int, g + LA>{});
+        wait_group(std::integral_constant<int, g>{}, std::integral_constant<int, reads_after(g)>{});
+        if constexpr (g < NG_QK) {
+          mma_group(std::integral_constant<int, g>{}, sn);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int ofs = kb * 32 * 128 + kfrag_row + (((2 * ks + half) ^ kfrag_sw) << 4);
-        const h8_t kh = *(const h8_t*)(kb_base + ofs);
-        if constexpr (SPLIT) {
-          const h8_t kl = *(const h8_t*)(kb_base + TILE_B + ofs);
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], ks == 0 ? negm : sacc[kb], 0, 0, 0);
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc[kb], 0, 0, 0);
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc[kb], 0, 0, 0);
+          for (int e = exp_first(g); e < exp_first(g) + exp_count(g); ++e) {
+#if ZK_ATT_ABL & 4
+            const float p = sc[e >> 4][e & 15];
+#else
+            const float p = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15]);
+#endif
+            psum += p;
+            pf[e >> 4][(e & 15) >> 3][e & 7] = (half_t)p;
+          }
         } else {
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], ks == 0 ? negm : sacc[kb], 0, 0, 0);
+          constexpr int v = g - NG_QK, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
+          oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[g % (LA + 1)].a), pf[kb][sx],
+                                                            oacc[mb], 0, 0, 0);
+          if constexpr (!LAST) {
+#pragma unroll
+            for (int e = 4 * v; e < 4 * v + 4; ++e) {
+              constexpr int dummy = 0; (void)dummy;
+              const int kbn = e >> 4, r = e & 15;
+              if constexpr (MASKNEXT) {
+                const int key = (NKT - 1) * KT + kbn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= S_) sn[kbn][r] = -1e30f;
+              }
+              mxp = fmaxf(mxp, sn[kbn][r]);
+            }
+          }
         }
-      }
-    }
-
-    // ---- online softmax (log2 domain); lane = query, registers = keys ----
-    if (kt == NKT - 1) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (key >= S_) sacc[kb][r] = -1e30f;
-        }
-    }
-    float mx = fmaxf(sacc[0][0], sacc[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    if (kt == 0 || !__all(mx <= RESCALE_THR)) {
-      const float delta = (kt == 0) ? mx : fmaxf(mx, 0.f);
-      const float alpha = (kt == 0) ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-      m_run += delta;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sacc[0][r] -= delta; sacc[1][r] -= delta; }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; negm[i] = -m_run; }
-      l_run *= alpha;
-    }
-    float psum = 0.f;
-    h8_t pf[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(sacc[kb][r]);
-        psum += p;
-        pf[kb][r >> 3][r & 7] = (half_t)p;
-      }
-    l_run += psum;
-
-    // ---- Oᵀ[d][q] += Vᵀ · Pᵀ ----
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-          const int key0 = kb * 32 + 16 * s + v_key;
-          const int a0 = key0 * 128 + (((4 * mb + v_chunk) ^ v_sw) << 4) + v_byte;
-          const s4v_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s4v_t*)(vb_base + a0));
-          const s4v_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s4v_t*)(vb_base + a0 + 8 * 128));
-          const h4_t x0 = __builtin_bit_cast(h4_t, t0), x1 = __builtin_bit_cast(h4_t, t1);
-          const h8_t vt = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-          oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt, pf[kb][s], oacc[mb], 0, 0, 0);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      l_run += psum;
+      if constexpr (!LAST) mx = fmaxf(mxp, __shfl_xor(mxp, 32, 64));
     }   // wave_active
 
-    if (kt + 1 < NKT) store_tile(cur ^ 1);
-    __syncthreads();
+    if constexpr (!LAST) {
+      // everything but this iteration's own pieces has landed (K(t+2), V(t+1): what iteration t+1 reads)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_ITER) : "memory");
+#if !(ZK_ATT_ABL & 2)
+      __builtin_amdgcn_s_barrier();      // (no __syncthreads: its fence would wait for this iteration's pieces as well)
+#endif
+      kslot = s1;
+    }
+  };
+  static_assert((NKT - 1) % 2 == 0, "the tile loop runs in pairs (the two score tiles swap roles)");
+  using F = std::false_type;
+  using T = std::true_type;
+  for (int kt = 0; kt < NKT - 3; kt += 2) {
+    iteration(kt, sA, sB, F{}, F{});
+    iteration(kt + 1, sB, sA, F{}, F{});
   }
+  iteration(NKT - 3, sA, sB, F{}, F{});
+  iteration(NKT - 2, sB, sA, F{}, T{});
+  iteration(NKT - 1, sA, sB, T{}, F{});
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the surplus pieces of the last iterations)
   // ---- finalize: O / l, store 4 consecutive d per register group ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -278,11 +474,15 @@ void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit
   if (n_windows <= 0) return;
   if (q_tiles <= 0 || q_tiles > NQT) q_tiles = NQT;   // q_tiles < 10: only the first q_tiles*128 query rows (last-layer pruning)
   const int grid = q_tiles * ZK_HEADS * n_windows;
-  if (nsplit == 3) {
-    hipLaunchKernelGGL(attention_kernel<3>, dim3(grid), dim3(256), 2 * 3 * TILE_B, s, qkv.hi, qkv.lo, out.hi, out.lo,
-                       n_windows, q_tiles, out.lo_fmt);
-  } else {
-    hipLaunchKernelGGL(attention_kernel<1>, dim3(grid), dim3(256), 2 * 2 * TILE_B, s, qkv.hi, qkv.lo, out.hi, out.lo,
-                       n_windows, q_tiles, out.lo_fmt);
-  }
+  auto go = [&](auto kernel, int lds) {
+    static bool attr[4] = {false, false, false, false};      // (the 3-deep rings of the split kernels exceed the 64 KiB default)
+    if (!attr[nsplit & 3]) {
+      (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr[nsplit & 3] = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, q_tiles, out.lo_fmt);
+  };
+  if (nsplit == 2) go(attention_kernel<2>, 3 * 3 * TILE_B);
+  else if (nsplit == 3) go(attention_kernel<3>, 3 * 3 * TILE_B);
+  else go(attention_kernel<1>, 3 * 2 * TILE_B);
 }

@@ -285,9 +285,10 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
         }
       }
     } else {
-      // STORE (fused QKV): the lo plane stays fp16 — q and k feed the split QK^T of attention.hip.
+      // STORE (fused QKV): q keeps an fp16 lo plane (attention.hip rescales and re-splits it), k gets the c8 byte pairs
+      // of the fp8-corrected QK^T (columns >= lo_c8_from), v has no lo plane (n >= lo_n_limit).
       // GELU (FC1 -> FC2 operand): the lo plane is the c8 byte pair.
-      constexpr int LOFMT = (EPI == ZK_EPI_GELU) ? ZK_LO_C8 : ZK_LO_F16;
+      const int LOFMT = (EPI == ZK_EPI_GELU || n0 >= a.lo_c8_from) ? ZK_LO_C8 : ZK_LO_F16;
       const bool want_lo = a.o_lo != nullptr && n0 < a.lo_n_limit;
 #pragma unroll
       for (int j = 0; j < RM; ++j) {

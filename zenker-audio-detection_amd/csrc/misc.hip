@@ -72,6 +72,22 @@ __global__ __launch_bounds__(256) void split_rows_c8_kernel(const float* __restr
   }
 }
 
+// columns [c0, c0 + ncols) of a [rows, ld] fp32 matrix -> activation c8 entries (test hooks / probes: the k columns of a
+// fused QKV matrix as the ZK_F16C8 QKV epilogue writes them)
+__global__ __launch_bounds__(256) void split_c8_cols_kernel(const float* __restrict__ src, int rows, int ld, int c0, int ncols,
+                                                            half_t* __restrict__ lo) {
+  const int per_row = ncols >> 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)rows * per_row) return;
+  const size_t at = (size_t)(i / per_row) * ld + c0 + 4 * (int)(i % per_row);
+  const f4_t v = *(const f4_t*)(src + at);
+  const float y[4] = {v[0], v[1], v[2], v[3]};
+  h4_t h;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h[j] = (half_t)y[j];
+  *(h4_t*)(lo + at) = zk_lo4(y, h, ZK_LO_C8);
+}
+
 // WAV sample decode + channel mean (load_audio, src/test_long_audio_windows_2stage.py:54-56): interleaved little-endian
 // samples -> one mono float32 per frame.  fmt: 1 = integer PCM (8 unsigned / 16 / 24 / 32 bit), 3 = IEEE float (32 / 64).
 // Scaling as torchaudio.load(normalize=True): x / 2^(bits-1) (8-bit: (x-128)/128); channel mean = fp32 sum in channel
@@ -147,6 +163,12 @@ void zk_launch_resample(const float* in, int64_t n_in, int orig, int neu, int wi
 void zk_launch_split_rows_c8(const float* src, int rows, int K, half_t* hi, half_t* c8, int32_t* rowexp, hipStream_t s) {
   if (rows <= 0) return;
   hipLaunchKernelGGL(split_rows_c8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, rows, K, hi, c8, rowexp);
+}
+
+void zk_launch_split_c8_cols(const float* src, int rows, int ld, int c0, int ncols, half_t* lo, hipStream_t s) {
+  if (rows <= 0 || ncols <= 0) return;
+  const long long n = (long long)rows * (ncols >> 2);
+  hipLaunchKernelGGL(split_c8_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, ld, c0, ncols, lo);
 }
 
 void zk_launch_split_c8(const float* src, int64_t n, int w_exp, int is_weight, half_t* c8, hipStream_t s) {

@@ -128,7 +128,7 @@ int zkp_bench_gemm_c8(int M, int N, int K, int epi, int variants, int iters, int
     zk_gemm_args a;
     a.x_hi = xh; a.x_lo = xl; a.w_hi = wh; a.w_lo = wl; a.bias = bias; a.x_rowexp = nullptr; a.M = M; a.N = N; a.K = K;
     a.o_hi = oh[v]; a.o_lo = ol[v]; a.resid = resid[v]; a.pos = nullptr; a.lo_n_limit = epi == ZK_EPI_STORE ? (2 * N) / 3 : N;
-    a.w_exp = w_exp;
+    a.w_exp = w_exp; a.lo_c8_from = epi == ZK_EPI_STORE ? N / 3 : 1 << 30;
     return a;
   };
   auto launch = [&](int v) {
@@ -213,7 +213,7 @@ int zkp_fill_probe(int M, int N, int K, int depth, int fix, int rounds, float* m
   return 0;
 }
 
-// attention alone on random device-resident planes: ms per launch (median of rounds), nsplit 3 (split QK^T) or 1
+// attention alone on random device-resident planes: ms per launch (median of rounds), nsplit 3 (split QK^T), 2 (fp8-corrected QK^T) or 1
 int zkp_bench_attention(int n_windows, int nsplit, int iters, int rounds, float* ms_out) {
   hipStream_t s;
   CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -224,6 +224,7 @@ int zkp_bench_attention(int n_windows, int nsplit, int iters, int rounds, float*
   CK(hipMalloc((void**)&oh, no * 2)); CK(hipMalloc((void**)&ol, no * 2));
   hipLaunchKernelGGL(fill_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, f, (int64_t)nq, 7u, 1.0f);
   zk_launch_split_f32(f, (int64_t)nq, 1.f, qh, ql, s);
+  if (nsplit == 2) zk_launch_split_c8_cols(f, (int)rows, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_HIDDEN, ql, s);
   CK(hipStreamSynchronize(s));
   (void)hipFree(f);
   hipEvent_t e0, e1;
@@ -232,7 +233,7 @@ int zkp_bench_attention(int n_windows, int nsplit, int iters, int rounds, float*
   for (int r = 0; r < rounds + 1; ++r) {
     CK(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i)
-      zk_launch_attention(zk_planes{qh, nsplit == 3 ? ql : nullptr, ZK_LO_F16, nullptr}, zk_planes{oh, ol, ZK_LO_C8, nullptr}, n_windows, nsplit, 0, s);
+      zk_launch_attention(zk_planes{qh, nsplit >= 2 ? ql : nullptr, ZK_LO_F16, nullptr}, zk_planes{oh, ol, ZK_LO_C8, nullptr}, n_windows, nsplit, 0, s);
     CK(hipEventRecord(e1, s));
     CK(hipEventSynchronize(e1));
     float ms = 0.f;

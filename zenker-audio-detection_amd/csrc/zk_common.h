@@ -99,6 +99,7 @@ struct zk_gemm_args {
   float* resid;        // [M, N] fp32, in-place += (RESID) ; PATCH: hidden base
   const float* pos;    // PATCH: position embeddings [1214, 768]
   int lo_n_limit;      // STORE: write the lo plane only for n < lo_n_limit
+  int lo_c8_from;      // STORE (ZK_F16C8): columns lo_c8_from <= n < lo_n_limit get a c8 lo plane (k of the fused QKV), the rest fp16
   int w_exp;           // ZK_F16C8: the weight's c8 plane holds (fp8(W·2^w_exp), fp8((W-Wh)·2^(w_exp+11)))
 };
 
@@ -133,5 +134,7 @@ void zk_launch_split_f32(const float* src, int64_t n, float scale, half_t* hi, h
 // weights: c8 plane = (fp8(w·2^e), fp8((w - fp16(w))·2^(e+11))) byte pairs; activations (is_weight = 0): (fp8((x-xh)·2^11), fp8(x))
 void zk_launch_split_c8(const float* src, int64_t n, int w_exp, int is_weight, half_t* c8, hipStream_t s);
 // activations [rows, K] fp32 -> row-scaled fp16 + c8 planes and the row exponents (zk_planes::rowexp); K % 4 == 0
+// columns [c0, c0 + ncols) of a [rows, ld] fp32 matrix -> activation c8 entries at the same positions of `lo` (ncols % 4 == 0)
+void zk_launch_split_c8_cols(const float* src, int rows, int ld, int c0, int ncols, half_t* lo, hipStream_t s);
 void zk_launch_split_rows_c8(const float* src, int rows, int K, half_t* hi, half_t* c8, int32_t* rowexp, hipStream_t s);
 void zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s);

@@ -352,7 +352,7 @@ int ensure_workspace(zk_ctx* c, int windows, bool split) {
 }
 
 void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, int M, int N, int K, int epi, int nsplit,
-              zk_planes out, float* resid, const float* pos, int lo_n_limit) {
+              zk_planes out, float* resid, const float* pos, int lo_n_limit, int lo_c8_from = 1 << 30) {
   ProfScope ps(c, cls);
   if (c->prof) c->prof_flops[cls] += 2.0 * M * (double)N * K;
   zk_gemm_args a;
@@ -360,7 +360,7 @@ void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias,
   a.x_rowexp = (nsplit == ZK_F16C8) ? x.rowexp : nullptr;
   a.M = M; a.N = N; a.K = K;
   a.o_hi = out.hi; a.o_lo = (nsplit != ZK_F16) ? out.lo : nullptr;
-  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.w_exp = w.exp;
+  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.lo_c8_from = lo_c8_from; a.w_exp = w.exp;
   if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
   else zk_launch_gemm(a, epi, nsplit, c->stream);
 }
@@ -369,7 +369,7 @@ void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias,
 int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
   const int ns = sm.mode;
   const bool sp = ns != ZK_F16;
-  // lo-plane format of every GEMM operand: c8 byte pairs in ZK_F16C8; the QKV planes keep an fp16 lo (split QK^T)
+  // lo-plane format of every GEMM operand: c8 byte pairs in ZK_F16C8 (of the QKV planes only k's columns: attention.hip)
   const int lf = (ns == ZK_F16C8) ? ZK_LO_C8 : ZK_LO_F16;
   const int M = nb * ZK_SEQ;
   float* hidden = c->hidden.as<float>();
@@ -395,12 +395,12 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
     const bool last = (l == sm.n_layers - 1) && c->prune_last && c->tap_layer != l;
     { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, M, xn, sm.eps, c->stream); }
     run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, M, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv,
-             nullptr, nullptr, 2 * ZK_HIDDEN);
+             nullptr, nullptr, 2 * ZK_HIDDEN, ns == ZK_F16C8 ? ZK_HIDDEN : 1 << 30);      // (c8: k's lo plane is c8)
     {
       ProfScope ps(c, P_ATTN);
       const int qt = last ? 1 : 10;
       if (c->prof) c->prof_flops[P_ATTN] += (double)nb * ZK_HEADS * 4.0 * (qt == 1 ? 128.0 : (double)ZK_SEQ) * ZK_SEQ * ZK_HEAD_DIM;
-      zk_launch_attention(qkv, att, nb, sp ? 3 : 1, qt, c->stream);
+      zk_launch_attention(qkv, att, nb, ns == ZK_F16C8 ? 2 : (sp ? 3 : 1), qt, c->stream);
     }
     if (last) {
       zk_planes att_s = c->att_s.get(sp, lf), xn_s = c->xn_s.get(sp, lf), mid_s = c->mid_s.get(sp, lf);
@@ -1087,7 +1087,7 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   zk_gemm_args a;
   a.x_hi = xh; a.x_lo = nsplit != ZK_F16 ? xl : nullptr; a.w_hi = wh; a.w_lo = nsplit != ZK_F16 ? wl : nullptr; a.bias = dbias;
   a.x_rowexp = dexp;
-  a.M = M; a.N = N; a.K = K; a.o_hi = oh; a.o_lo = nsplit != ZK_F16 ? ol : nullptr; a.resid = dres; a.pos = dpos; a.lo_n_limit = N;
+  a.M = M; a.N = N; a.K = K; a.o_hi = oh; a.o_lo = nsplit != ZK_F16 ? ol : nullptr; a.resid = dres; a.pos = dpos; a.lo_n_limit = N; a.lo_c8_from = 1 << 30;
   a.w_exp = w_exp;
   if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
   else zk_launch_gemm(a, epi, nsplit, c->stream);
@@ -1123,8 +1123,10 @@ int zk_test_attention(zk_ctx* c, const float* qkv, int32_t W, int32_t nsplit, fl
   HIPCHK(c, hipMemcpy(dq, qkv, nq * 4, hipMemcpyHostToDevice));
   zk_launch_split_f32(dq, (int64_t)nq, 1.f, qh, ql, c->stream);
   const int lf = nsplit == ZK_F16C8 ? ZK_LO_C8 : ZK_LO_F16;
+  if (nsplit == ZK_F16C8)      // as the fused QKV epilogue of this mode leaves them: k's lo entries are c8 byte pairs
+    zk_launch_split_c8_cols(dq, (int)rows, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_HIDDEN, ql, c->stream);
   zk_launch_attention(zk_planes{qh, nsplit != ZK_F16 ? ql : nullptr, ZK_LO_F16}, zk_planes{oh, nsplit != ZK_F16 ? ol : nullptr, lf}, W,
-                      nsplit != ZK_F16 ? 3 : 1, 0, c->stream);
+                      nsplit == ZK_F16C8 ? 2 : (nsplit != ZK_F16 ? 3 : 1), 0, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<uint16_t> h(no), l(no);
