@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   for (int mb = 0; mb < 2; ++mb)
     vofs[mb] = lds0 + (unsigned)(V_OFF + v_key * 128 + (((4 * mb + v_chunk) ^ v_sw) << 4) + v_byte);
   unsigned ka[4], va[2];      // the same with the ring slots of the iteration added
-  auto nreads = [](int g) constexpr { return g >= NG_QK ? 2 : (C8 ? ((g % 6) < 2 ? 2 : 1) : (SPLIT ? 2 : 1)); };
+  auto nreads = [](int g) constexpr { return g >= NG_QK ? 2 : (C8 ? ((g >> 1) < 2 ? 2 : 1) : (SPLIT ? 2 : 1)); };
   auto reads_after = [nreads](int g) constexpr {
     int n = 0;
     for (int j = g + 1; j <= g + LA && j < NSLOT; ++j) n += nreads(j);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     kf_t& f = fr[g % (LA + 1)];
     if constexpr (g < NG_QK) {
       if constexpr (C8) {
-        constexpr int kb = g / 6, i = g % 6;
+        constexpr int kb = g & 1, i = g >> 1;      // the two 32-key blocks alternate: two independent accumulator chains
         if constexpr (i < 2) {      // c8 image, chunks of ks = 2i and 2i+1
           asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
                        : "=&v"(f.a), "=&v"(f.b) : "v"(ka[2 * i]), "v"(ka[2 * i + 1]), "n"(kb * 4096 + TILE_B));
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
           asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a) : "v"(ka[i - 2]), "n"(kb * 4096));
         }
       } else {
-        constexpr int kb = g / 4, ks = g % 4;
+        constexpr int kb = g & 1, ks = g >> 1;
         if constexpr (SPLIT)
           asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
                        : "=&v"(f.a), "=&v"(f.b) : "v"(ka[ks]), "n"(kb * 4096), "n"(kb * 4096 + TILE_B));
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     constexpr int g = decltype(gc)::value;
     const kf_t& f = fr[g % (LA + 1)];
     if constexpr (C8) {
-      constexpr int kb = g / 6, i = g % 6;
+      constexpr int kb = g & 1, i = g >> 1;      // the two 32-key blocks alternate: two independent accumulator chains
       if constexpr (i < 2) {
         const i8v_t kc = __builtin_shufflevector(f.a, f.b, 0, 1, 2, 3, 4, 5, 6, 7);
         sn[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kc, qc[i], i == 0 ? negm : sn[kb], 0, 0, 0,
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
         sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, f.a), qh[i - 2], sn[kb], 0, 0, 0);
       }
     } else {
-      constexpr int kb = g / 4, ks = g % 4;
+      constexpr int kb = g & 1, ks = g >> 1;
       const h8_t kh = __builtin_bit_cast(h8_t, f.a);
       if constexpr (SPLIT) {
         const h8_t kl = __builtin_bit_cast(h8_t, f.b);
@@ -288,8 +288,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     }
   };
   // first and count of the 32 exponentials that ride in score slot g
-  auto exp_first = [](int g) constexpr { return C8 ? (g / 6) * 16 + ((g % 6) < 2 ? 4 * (g % 6) : 8 + 2 * ((g % 6) - 2)) : 4 * g; };
-  auto exp_count = [](int g) constexpr { return C8 ? ((g % 6) < 2 ? 4 : 2) : 4; };
+  auto exp_count = [](int g) constexpr { return C8 ? ((g >> 1) < 2 ? 4 : 2) : 4; };
+  auto exp_first = [exp_count](int g) constexpr {
+    int n = 0;
+    for (int j = 0; j < g; ++j) n += exp_count(j);
+    return n;
+  };
 
   // a wave whose 32 query rows all lie beyond the sequence (the last query tile holds 62 of 128 rows: waves 2 and 3)
   // only takes part in the K/V staging and the barriers — its SIMD time goes to the other resident workgroup
@@ -349,6 +353,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     // piece every DMA_EVERY slots, between the MFMAs (a piece holds the issuing wave for ~100 cycles)
     constexpr int DMA_EVERY = NSLOT / PER_ITER;
     auto stage_piece = [&](int pc) __attribute__((always_inline)) {
+#if ZK_ATT_ABL & 8
+      if (pc & 1) return;      // (timing probe: half of the staging, wrong results)
+#endif
 #if !(ZK_ATT_ABL & 1)
       dma_piece(pc, kt + 3, s0, kt + 2, s2);
 #endif
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
 
     if constexpr (!LAST) {
       // everything but this iteration's own pieces has landed (K(t+2), V(t+1): what iteration t+1 reads)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_ITER) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ZK_ATT_ABL & 8) ? PER_ITER / 2 : PER_ITER) : "memory");
 #if !(ZK_ATT_ABL & 2)
       __builtin_amdgcn_s_barrier();      // (no __syncthreads: its fence would wait for this iteration's pieces as well)
 #endif

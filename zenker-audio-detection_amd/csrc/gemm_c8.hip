@@ -230,6 +230,14 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
       }
     }
     auto row_scale = [&](int j) __attribute__((always_inline)) { return scaled ? rsc[j * 16 + frow] : 1.0f; };
+#ifdef ZK_C8_NOEPI      // probe builds only (tools/build_variant.sh): the tile's results are dropped -> time of the k-loops alone
+    if (a.M > 0) {
+#pragma unroll
+      for (int i = 0; i < RN; ++i)
+#pragma unroll
+        for (int j = 0; j < RM; ++j) { asm volatile("" : "+v"(acc[i][j])); acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f}; }
+    } else
+#endif
     if constexpr (EPI == ZK_EPI_PATCH) {
 #pragma unroll
       for (int i = 0; i < RN; ++i)
