@@ -1,3 +1,3 @@
 set -e
-Z=zenker-audio-detection_amd/zkast
-ZKAST_PROBES=$Z/libzkast_probes_st8.so timeout -k 10 300 python tools/gemm_ab.py 512 3 4 3 > gpurun_out/st.log 2>&1
+timeout -k 10 300 python tools/gemm_ab.py 512 3 4 3 > gpurun_out/es.log 2>&1
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm" > gpurun_out/es_tests.log 2>&1

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512) void gemm_c8v1_kernel(const zk_gemm_args a) {
           f4_t v = acc[i][j] + b4[i];
           acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
           if constexpr (EPI == ZK_EPI_GELU) {
-            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+            v[0] = gelu_erf_as26(v[0]); v[1] = gelu_erf_as26(v[1]); v[2] = gelu_erf_as26(v[2]); v[3] = gelu_erf_as26(v[3]);
           }
           h4_t hi;
 #pragma unroll
