@@ -298,6 +298,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
       // GELU (FC1 -> FC2 operand): the lo plane is the c8 byte pair.
       const int LOFMT = (EPI == ZK_EPI_GELU || n0 >= a.lo_c8_from) ? ZK_LO_C8 : ZK_LO_F16;
       const bool want_lo = a.o_lo != nullptr && n0 < a.lo_n_limit;
+      [[maybe_unused]] const gelu_coef_t gk = gelu_coefficients();
 #pragma unroll
       for (int j = 0; j < RM; ++j) {
         h4_t lo4[RN];
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
           f4_t v = acc[i][j] * sj + b4[i];
           acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
           if constexpr (EPI == ZK_EPI_GELU) {
-            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+            const gelu_f2_t g01 = gelu_erf2(gelu_f2_t{v[0], v[1]}, gk), g23 = gelu_erf2(gelu_f2_t{v[2], v[3]}, gk);
+            v[0] = g01[0]; v[1] = g01[1]; v[2] = g23[0]; v[3] = g23[1];
           }
           h4_t hi;
 #pragma unroll

@@ -24,6 +24,29 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaxf(x, 0.0f) - u * s;
 }
 
+// two elements at a time: the Horner chain as v_pk_fma_f32 (hipcc turns the scalar form above into one v_fmaak_f32 per
+// coefficient and element, twice the issue slots)
+typedef float gelu_f2_t __attribute__((ext_vector_type(2)));
+struct gelu_coef_t { float c[9]; };
+// the coefficients as opaque scalar registers, fetched once per epilogue (an empty asm hides the literals: folded into the
+// instructions they would turn every packed fma back into two v_fmaak_f32)
+__device__ __forceinline__ gelu_coef_t gelu_coefficients() {
+  gelu_coef_t k = {{9.999988675e-01f, 1.151123285e+00f, 4.591154456e-01f, 5.271420255e-02f, -7.333386224e-03f,
+                    3.233428288e-04f, 1.144626513e-04f, -2.508334364e-05f, 1.690407657e-06f}};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) asm volatile("" : "+s"(k.c[i]));
+  return k;
+}
+__device__ __forceinline__ gelu_f2_t gelu_erf2(gelu_f2_t x, const gelu_coef_t& k) {
+  const gelu_f2_t u = {fminf(fabsf(x[0]), 8.0f), fminf(fabsf(x[1]), 8.0f)};
+  gelu_f2_t p = {k.c[8], k.c[8]};
+#pragma unroll
+  for (int i = 7; i >= 0; --i) p = __builtin_elementwise_fma(p, u, gelu_f2_t{k.c[i], k.c[i]});
+  const gelu_f2_t s2 = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
+  const gelu_f2_t r = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+  return r - u * s2;
+}
+
 // the round-1 formulation (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7 on erf), kept for the frozen A/B kernel
 __device__ __forceinline__ float gelu_erf_as26(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
