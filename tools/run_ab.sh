@@ -1,3 +1,3 @@
 set -e
-AB_ONLY=fc1 timeout -k 10 300 python tools/gemm_ab.py 512 3 4 3 > gpurun_out/gelu.log 2>&1
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm" > gpurun_out/gelu_tests.log 2>&1
+timeout -k 10 120 python tools/gemm_c6_ab.py 8 2 1 > gpurun_out/c6_small.log 2>&1
+timeout -k 10 400 python tools/gemm_c6_ab.py 512 4 3 > gpurun_out/c6.log 2>&1

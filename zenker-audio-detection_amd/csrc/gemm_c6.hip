@@ -1,0 +1,508 @@
+// PROBE VARIANT (libzkast_probes.so only): the correction pass on MX-fp6 (e2m3, one e8m0 scale per (row, 16 k))
+// planes instead of fp8 byte pairs: 96-byte rows per 64-k ring step, 12-byte LDS-DMA pieces, ds_read_b64 x 3 fragments,
+// per-lane scale bytes, v_mfma_scale_f32_16x16x128_f8f6f4 with cbsz = blgp = 2 (16 cycles instead of 32).  Derived
+// from gemm_c8.hip; its comments below describe the common structure.
+//
+// MFMA GEMM, "fp16 + fp8-corrected" mode (ZK_F16C8):  out[M,N] = X[M,K] · W[N,K]^T + bias  (+ fused epilogue)
+//
+// Same role as gemm.hip (every nn.Linear of ASTAttention / ASTMLP and the patch-embedding Conv2d-as-GEMM,
+// $TF/models/audio_spectrogram_transformer/modeling_audio_spectrogram_transformer.py:57-61,140-143,174,187-192) and the
+// same fp32-grade product, at 2 matrix-pipe passes instead of 3:
+//
+//     X·W = Xh·Wh + (Xl·W + X·Wl) + O(2^-22),        Xh = fp16(X), Xl = X - Xh  (|Xl| <= 2^-11 |X|), same for W.
+//
+// The bracket is 2^-11 of the result, so 4 significant bits are plenty for it.  Each operand therefore carries, next
+// to its fp16 plane, a "c8" plane of byte pairs  X' = (fp8(Xl·2^11), fp8(X)),  W' = (fp8(W·2^e), fp8(Wl·2^(e+11)))
+// (OCP e4m3).  Read as rows of 2K bytes, X'·W'^T IS the bracket times 2^(e+11): one fp8 GEMM with K' = 2K on
+// v_mfma_scale_f32_16x16x128_f8f6f4, whose A-side block scale 2^-(e+11) puts it straight into the accumulator of
+// the fp16 product (2x the fp16 rate -> the K' = 2K product costs one fp16 pass).
+//
+// gfx950 structure (differences to gemm.hip):
+//  * a ring step is 64 k-elements = 128-byte rows for BOTH plane kinds (fp16: 64 x 2 B, c8: 64 x 2 B), 64 KiB per
+//    step, two ring slots.  Steps alternate  main(k) -> slot 0,  corr(k) -> slot 1,  so slot, plane and MFMA kind of
+//    a step are compile-time constants of a 2x-unrolled loop.
+//  * a lane's fragment of a 16-row tile is 32 bytes of its row: 16-B chunks q and q+4 (q = lane>>4) of the
+//    XOR-swizzled row image (conflict-free ds_read_b128 pair).  Both operands use the same K permutation, which is
+//    all an MFMA needs; the fp16 step feeds the two halves to two 16x16x32 MFMAs, the fp8 step feeds all 8 VGPRs
+//    to one 16x16x128 MFMA.
+//  * W-stationary: the 4 W fragments of the wave's 64 columns stay in registers for the whole step, the 8 X
+//    fragments stream through a 2-deep register buffer (24 ds_read_b128 per step and wave).  The last X tile of a
+//    step is multiplied AFTER the step's barrier, behind the first fragment reads of the next step.
+#include <type_traits>
+
+#include "gemm_util.h"
+#include "gemm_c6.h"
+
+namespace {
+
+// the 8 LDS-DMA pieces a wave issues per step: 2 in the deferred tile right behind the step barrier (chunk -1), 2 in
+// each of chunks 0..2 (measured best of four placements; a piece costs ~100 issue cycles among MFMAs)
+constexpr int c8_cnt(int c) {
+  constexpr int T[8] = {2, 2, 2, 2, 0, 0, 0, 0};
+  return T[c + 1];
+}
+constexpr int c8_base(int c) { int b = 0; for (int q = -1; q < c; ++q) b += c8_cnt(q); return b; }
+// piece to issue in front of MFMA group g (of G) of chunk c, or -1
+constexpr int c8_piece(int c, int g, int G) {
+  const int n = c8_cnt(c);
+  for (int q = 0; q < n; ++q) if (q * G / n == g) return c8_base(c) + q;
+  return -1;
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I in [0, N) — the loop index ends up in "n" asm operands
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+typedef int i2v_t __attribute__((ext_vector_type(2)));
+typedef int i4v_t __attribute__((ext_vector_type(4)));
+typedef int i8v_t __attribute__((ext_vector_type(8)));
+struct frag_t { i4v_t a, b; };
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_c6_kernel(const zk_gemm6_args a6) {
+  const zk_gemm_args& a = a6.a;
+  constexpr int BM = 256, BN = 256, BK = 64, WM = 2, WN = 4;
+  constexpr int ROWB = 128, CPR = 8, RPI = 8;
+  constexpr int TM = BM / WM, TN = BN / WN;       // 128 x 64 per wave
+  constexpr int RM = TM / 16, RN = TN / 16;       // 8 X tiles, 4 W tiles
+  constexpr int XBYTES = BM * ROWB, WBYTES = BN * ROWB, STAGE = XBYTES + WBYTES;
+  constexpr int XI = BM / RPI / 8, WI = BN / RPI / 8, LPT = XI + WI;   // 1-KiB LDS-DMA pieces per wave and step
+  constexpr int BIAS_OFF = 2 * STAGE;
+  constexpr int SCR_OFF = BIAS_OFF + 2 * 8 * 256;
+  constexpr int SCR_STR = 144, SCR_WAVE = 16 * SCR_STR;
+  constexpr int RSC_OFF = SCR_OFF + 8 * SCR_WAVE;      // per wave: 128 row scales (fp32) of its X rows, epilogue only
+  constexpr int TILE_B = 16 * ROWB;               // 2048 B between consecutive 16-row tiles
+  // c6 slot (= slot 1): X image 256 rows x 96 B, W image behind it, then 1 KiB of X block scales ([row][4]) and 1 KiB of W's
+  constexpr int ROW6 = 96, X6BYTES = BM * ROW6, TILE6_B = 16 * ROW6;
+  constexpr int XS_OFF = STAGE + 2 * X6BYTES;      // (W scales follow at + 1024)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_n = a.N / BN;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = a.K / BK;
+  const int per = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int first = xcd * per + jb;
+  const int stride = 8 * per;
+  const int my_tiles = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+  const int total = my_tiles * nk * 2;
+  if (total == 0) return;
+
+  // ---- staging ----
+  const int srow = lane / CPR, schunk = lane % CPR;
+  int l_step = 0, l_k = 0, l_ord = 0, l_tile = first;
+  int l_m0 = (first / tiles_n) * BM, l_n0 = (first % tiles_n) * BN;
+  // (probe variant: the X planes are allocated in whole 256-row tiles, so no row clamp is needed and piece q of either
+  // operand reads at  base + q·64 rows + ONE per-lane offset — the 16-B chunk swizzle (row >> 1) & 7 does not depend on q)
+  const int prow = wave * RPI + srow;
+  unsigned poff0 = (unsigned)prow * (unsigned)(a.K * 2) + (unsigned)((schunk ^ ((prow >> 1) & (CPR - 1))) * 16);
+  // fp6 planes: rows of K·3/2 bytes, 12-byte chunks; LDS pair position q of a row holds source pair q ^ 2·((row >> 3) & 1)
+  // (the fragment reads want the 24-byte blocks of rows r and r+8 on different banks); (row >> 3) & 1 = wave & 1
+  unsigned poff6 = (unsigned)prow * (unsigned)(a.K * 3 / 2) +
+                   (unsigned)((2 * ((schunk >> 1) ^ (2 * (wave & 1))) + (schunk & 1)) * 12);
+  // piece `pc` of the step at the load cursor; KIND (0 = fp16 planes -> slot 0, 1 = c8 planes -> slot 1) is static.
+  // Pieces are UNCONDITIONAL so that a ring step is one basic block (hipcc otherwise sinks the MFMAs of a step below
+  // all of its memory instructions): once the cursor has run past the last step it stays on it and the pieces
+  // re-fetch that step into the slot nobody reads any more.
+  // c6 pieces: 768 B = 8 rows x 96 B, lane -> (row = lane >> 3, 12-byte LDS chunk = lane & 7)
+  auto issue_piece = [&](auto kind_c, int pc) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    if constexpr (KIND == 0) {
+      char* base = smem;
+      const int k0 = l_k * BK;
+      if (pc < XI) {
+        const int instr = pc * 8 + wave;
+        const char* gb = uniform_ptr((const char*)(a.x_hi + ((size_t)l_m0 + pc * 64) * a.K + k0));
+        asm volatile("" : "+v"(poff0));      // keep the offset a 32-bit VGPR: SGPR-base + voffset addressing
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + poff0),
+                                         (__attribute__((address_space(3))) void*)(base + instr * 1024), 16, 0, 0);
+      } else {
+        const int instr = (pc - XI) * 8 + wave;
+        const char* gb = uniform_ptr((const char*)(a.w_hi + ((size_t)l_n0 + (pc - XI) * 64) * a.K + k0));
+        asm volatile("" : "+v"(poff0));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + poff0),
+                                         (__attribute__((address_space(3))) void*)(base + XBYTES + instr * 1024), 16, 0, 0);
+      }
+      if (pc == 0) {      // the tile's bias slice rides along with every fp16 step (256 B per wave)
+        const char* bsrc = uniform_ptr((const char*)(a.bias + l_n0 + wn * TN));
+        unsigned boff;      // lane * 4, recomputed per use
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 2, %0" : "=&v"(boff));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + boff),
+                                         (__attribute__((address_space(3))) void*)(smem + BIAS_OFF +
+                                                                                   ((l_ord & 1) * 8 + wave) * 256),
+                                         4, 0, 0);
+      }
+    } else {
+      char* base = smem + STAGE;
+      const size_t krow = (size_t)a.K * 3 / 2;      // bytes per plane row
+      if (pc < XI) {
+        const int instr = pc * 8 + wave;
+        const char* gb = uniform_ptr((const char*)a.x_lo + ((size_t)l_m0 + pc * 64) * krow + l_k * ROW6);
+        asm volatile("" : "+v"(poff6));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + poff6),
+                                         (__attribute__((address_space(3))) void*)(base + instr * 768), 12, 0, 0);
+      } else {
+        const int instr = (pc - XI) * 8 + wave;
+        const char* gb = uniform_ptr((const char*)a.w_lo + ((size_t)l_n0 + (pc - XI) * 64) * krow + l_k * ROW6);
+        asm volatile("" : "+v"(poff6));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + poff6),
+                                         (__attribute__((address_space(3))) void*)(base + X6BYTES + instr * 768), 12, 0, 0);
+      }
+      if (pc == 0) {      // block scales of the step: waves 0-3 the 1 KiB of X's ([row][4]), waves 4-7 W's (4 B per lane)
+        const unsigned long long xsp = (unsigned long long)(a6.xs + ((size_t)l_k * a6.m_pad + l_m0) * 4 + wave * 256);
+        const unsigned long long wsp = (unsigned long long)(a6.ws + ((size_t)l_k * a.N + l_n0) * 4 + (wave - 4) * 256);
+        const unsigned long long m = 0ull - (unsigned long long)(wave < 4 ? 1 : 0);      // branch-free select
+        const char* gb = uniform_ptr((const char*)((xsp & m) | (wsp & ~m)));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(smem + XS_OFF + wave * 256), 4, 0, 0);
+      }
+    }
+  };
+  auto advance_load = [&](auto kind_c) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    ++l_step;
+    if (KIND == 1 && l_step < total) {      // past the end the cursor stays on the last step (see issue_piece)
+      if (++l_k == nk) {
+        l_k = 0; ++l_ord; l_tile += stride;
+        const int tm = l_tile / tiles_n;
+        l_m0 = tm * BM; l_n0 = (l_tile - tm * tiles_n) * BN;
+      }
+    }
+  };
+
+  f4_t acc[RN][RM];
+#pragma unroll
+  for (int i = 0; i < RN; ++i)
+#pragma unroll
+    for (int j = 0; j < RM; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: row = tile_base + (lane&15), chunks q and q+4 of the swizzled row
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  const int fsw = (lane >> 1) & 7;
+  const int xoff = (wm * TM + frow) * ROWB + ((fq ^ fsw) & 7) * 16;
+  const int woff = XBYTES + (wn * TN + frow) * ROWB + ((fq ^ fsw) & 7) * 16;
+  // Fragment reads are inline asm with HAND-COUNTED s_waitcnt lgkmcnt: hipcc's own placement waits lgkmcnt(0) in front
+  // of a chunk's first MFMA, i.e. also for the two reads of the NEXT tile issued just before — an exposed LDS round
+  // trip per chunk.  LDS reads retire in order, so "all but the newest two" is lgkmcnt(2).  The wait statements name
+  // the fragments they make valid as in/out operands so that no MFMA can be scheduled in front of them.
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;      // LDS byte address of the ring (low half of the flat address)
+  const unsigned xad[2] = {lds0 + (unsigned)xoff, lds0 + (unsigned)(xoff ^ 64)};
+  // W fragment addresses = X fragment addresses + a wave-uniform distance, added at use (volatile: a hoisted copy would
+  // cost a VGPR per address for the whole kernel)
+  const int d_w = woff - xoff;
+  // fp6 slot: a lane's fragment = the 24-byte block (row, fq) = 3 x ds_read_b64 (pair-position swizzle, see issue_piece:
+  // conflict-free) + its e8m0 scale byte; registers: a = bytes 0-15, b = (bytes 16-23, scale, -)
+  const unsigned pair6 = (unsigned)((fq ^ (2 * ((frow >> 3) & 1))) * 24);
+  const unsigned x6ad = lds0 + (unsigned)(STAGE + (wm * TM + frow) * ROW6) + pair6;
+  const int d_w6 = X6BYTES + (wn * TN - wm * TM) * ROW6;
+  const unsigned xsad = lds0 + (unsigned)(XS_OFF + (wm * TM + frow) * 4 + fq);
+  const int d_ws = 1024 + (wn * TN - wm * TM) * 4;
+  auto ld_frag = [&](frag_t& f, auto slot_c, auto isw_c, auto tile_c) __attribute__((always_inline)) {
+    constexpr bool ISW = decltype(isw_c)::value;
+    if constexpr (decltype(slot_c)::value == 0) {
+      constexpr int IMM = decltype(tile_c)::value * TILE_B;
+      if constexpr (ISW) {
+        unsigned a0, a1;
+        asm volatile("v_add_u32 %0, %2, %4\n\tv_add_u32 %1, %3, %4" : "=&v"(a0), "=&v"(a1) : "v"(xad[0]), "v"(xad[1]), "s"(d_w));
+        asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
+                     : "=&v"(f.a), "=&v"(f.b)
+                     : "v"(a0), "v"(a1), "n"(IMM));
+      } else {
+        asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
+                     : "=&v"(f.a), "=&v"(f.b)
+                     : "v"(xad[0]), "v"(xad[1]), "n"(IMM));
+      }
+    } else {
+      constexpr int IMM = decltype(tile_c)::value * TILE6_B, SIMM = decltype(tile_c)::value * 64;
+      i2v_t p0, p1, p2;
+      int sc;
+      unsigned d6 = x6ad, ds = xsad;
+      if constexpr (ISW) asm volatile("v_add_u32 %0, %2, %4\n\tv_add_u32 %1, %3, %5" : "=&v"(d6), "=&v"(ds) : "v"(x6ad), "v"(xsad), "s"(d_w6), "s"(d_ws));
+      asm volatile("ds_read_b64 %0, %4 offset:%6\n\tds_read_b64 %1, %4 offset:%7\n\tds_read_b64 %2, %4 offset:%8\n\t"
+                   "ds_read_u8 %3, %5 offset:%9"
+                   : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(sc)
+                   : "v"(d6), "v"(ds), "n"(IMM), "n"(IMM + 8), "n"(IMM + 16), "n"(SIMM));
+      f.a = __builtin_shufflevector(p0, p1, 0, 1, 2, 3);
+      f.b = i4v_t{p2[0], p2[1], sc, 0};
+    }
+  };
+  // HALF: fp16 kind: 0 / 1 = first / second 32-deep MFMA of the 64-deep step (issued as two sweeps over the W tiles, so
+  // consecutive MFMAs never depend on each other); fp6 kind: one MFMA over the 128 codes of the step (HALF 0 only), the
+  // lanes' block scales as its scale operands
+  auto mma = [&](auto kind_c, auto half_c, f4_t& c, const frag_t& w, const frag_t& x) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    constexpr int HALF = decltype(half_c)::value;
+    if constexpr (KIND == 0) {
+      if constexpr (HALF == 0)
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, w.a), __builtin_bit_cast(h8_t, x.a), c, 0, 0, 0);
+      else
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, w.b), __builtin_bit_cast(h8_t, x.b), c, 0, 0, 0);
+    } else if constexpr (HALF == 0) {
+      const i8v_t wv = __builtin_shufflevector(w.a, w.b, 0, 1, 2, 3, 4, 5, 6, 7);
+      const i8v_t xv = __builtin_shufflevector(x.a, x.b, 0, 1, 2, 3, 4, 5, 6, 7);
+      c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, xv, c, 2, 2, 0, w.b[2], 0, x.b[2]);
+    }
+  };
+
+  frag_t wf[RN];      // W tiles of the current step
+  frag_t xf[2];       // X tile j lives in xf[j & 1]
+
+  int c_ord = 0, c_tile = first;
+  // ---- epilogue (accumulator layout and LDS-transposed stores as in gemm.hip) ----
+  char* scr = smem + SCR_OFF + wave * SCR_WAVE;
+  const int rd_row = lane >> 3, rd_ch = lane & 7;
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const int tm = c_tile / tiles_n, tn = c_tile - tm * tiles_n;
+    const int m0 = tm * BM + wm * TM, n0 = tn * BN + wn * TN;
+    const char* bslot = smem + BIAS_OFF + ((c_ord & 1) * 8 + wave) * 256;
+    f4_t b4[RN];
+#pragma unroll
+    for (int i = 0; i < RN; ++i) b4[i] = *(const f4_t*)(bslot + (i * 16 + 4 * fq) * 4);
+    // row-scaled X planes (zk_planes::rowexp): accumulator row m is multiplied by 2^s_m — folded into the bias add as
+    // one fma per element.  The wave's 128 scales go through LDS so that one VGPR at a time holds them.
+    const bool scaled = a.x_rowexp != nullptr;
+    float* rsc = (float*)(smem + RSC_OFF + wave * 512);
+    if (scaled) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        int m = m0 + t * 64 + lane;
+        m = m < a.M ? m : a.M - 1;
+        rsc[t * 64 + lane] = __int_as_float((a.x_rowexp[m] + 127) << 23);
+      }
+    }
+    auto row_scale = [&](int j) __attribute__((always_inline)) { return scaled ? rsc[j * 16 + frow] : 1.0f; };
+#ifdef ZK_C8_NOEPI      // probe builds only (tools/build_variant.sh): the tile's results are dropped -> time of the k-loops alone
+    if (a.M > 0) {
+#pragma unroll
+      for (int i = 0; i < RN; ++i)
+#pragma unroll
+        for (int j = 0; j < RM; ++j) { asm volatile("" : "+v"(acc[i][j])); acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f}; }
+    } else
+#endif
+    if constexpr (EPI == ZK_EPI_PATCH) {
+#pragma unroll
+      for (int i = 0; i < RN; ++i)
+#pragma unroll
+        for (int j = 0; j < RM; ++j) {
+          const int m = m0 + j * 16 + frow, n = n0 + i * 16 + 4 * fq;
+          f4_t v = acc[i][j] * row_scale(j) + b4[i];
+          acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+          // pin v in front of the divergent tail guard: hipcc otherwise sinks the MFMA that produces acc[i][j] into
+          // the guarded block, where it would run with a partial EXEC mask (wrong A/B rows from the masked lanes)
+          asm volatile("" : "+v"(v));
+          if (m >= a.M) continue;
+          const int b = m / ZK_NPATCH, p = m - b * ZK_NPATCH;
+          const f4_t pe = *(const f4_t*)(a.pos + (size_t)(p + 2) * a.N + n);
+          *(f4_t*)(a.resid + ((size_t)b * ZK_SEQ + 2 + p) * a.N + n) = v + pe;
+        }
+    } else if constexpr (EPI == ZK_EPI_RESID) {
+      // fp32 residual read-modify-write.  The residual reads of TWO 16-row blocks (8 x 16 B per lane) are issued
+      // together, unguarded (rows clamped to M-1), in front of the LDS transposes that consume them: one exposed HBM
+      // round trip per 32 rows instead of one per 8 (the guarded load -> add -> store chain was latency-bound:
+      // ~49 k cycles per tile, more than a third of the O projection's time).
+#pragma unroll
+      for (int jb = 0; jb < RM; jb += 2) {
+        f4_t hv[2][2][2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              int m = m0 + (jb + jj) * 16 + rd_row + 8 * t;
+              m = m < a.M ? m : a.M - 1;
+              hv[jj][hf][t] = *(const f4_t*)(a.resid + (size_t)m * a.N + n0 + hf * 32 + rd_ch * 4);
+            }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = jb + jj;
+          const float sj = row_scale(j);
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int il = 0; il < 2; ++il) {
+              *(f4_t*)(scr + frow * SCR_STR + il * 64 + fq * 16) = acc[hf * 2 + il][j] * sj + b4[hf * 2 + il];
+              acc[hf * 2 + il][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const f4_t v = *(const f4_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+              const int m = m0 + j * 16 + rd_row + 8 * t;
+              if (m < a.M) *(f4_t*)(a.resid + (size_t)m * a.N + n0 + hf * 32 + rd_ch * 4) = hv[jj][hf][t] + v;
+            }
+          }
+        }
+      }
+    } else {
+      // STORE (fused QKV): q keeps an fp16 lo plane (attention.hip rescales and re-splits it), k gets the c8 byte pairs
+      // of the fp8-corrected QK^T (columns >= lo_c8_from), v has no lo plane (n >= lo_n_limit).
+      // GELU (FC1 -> FC2 operand): the lo plane is the c8 byte pair.
+      const int LOFMT = (EPI == ZK_EPI_GELU || n0 >= a.lo_c8_from) ? ZK_LO_C8 : ZK_LO_F16;
+      const bool want_lo = a.o_lo != nullptr && n0 < a.lo_n_limit;
+      [[maybe_unused]] const gelu_coef_t gk = gelu_coefficients();
+#pragma unroll
+      for (int j = 0; j < RM; ++j) {
+        h4_t lo4[RN];
+        const float sj = row_scale(j);
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+          f4_t v = acc[i][j] * sj + b4[i];
+          acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+          if constexpr (EPI == ZK_EPI_GELU) {
+            const gelu_f2_t g01 = gelu_erf2(gelu_f2_t{v[0], v[1]}, gk), g23 = gelu_erf2(gelu_f2_t{v[2], v[3]}, gk);
+            v[0] = g01[0]; v[1] = g01[1]; v[2] = g23[0]; v[3] = g23[1];
+          }
+          h4_t hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hi[e] = (half_t)v[e];
+          const float vv[4] = {v[0], v[1], v[2], v[3]};
+          lo4[i] = zk_lo4(vv, hi, LOFMT);
+          *(h4_t*)(scr + frow * SCR_STR + i * 32 + fq * 8) = hi;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+          const int m = m0 + j * 16 + rd_row + 8 * t;
+          if (m < a.M) *(h8_t*)(a.o_hi + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+        }
+        if (want_lo) {
+#pragma unroll
+          for (int i = 0; i < RN; ++i) *(h4_t*)(scr + frow * SCR_STR + i * 32 + fq * 8) = lo4[i];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+            const int m = m0 + j * 16 + rd_row + 8 * t;
+            if (m < a.M) *(h8_t*)(a.o_lo + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+          }
+        }
+      }
+    }
+    ++c_ord; c_tile += stride;
+  };
+
+
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using H0 = K0;
+  using H1 = K1;
+
+  // prologue: step 0 (main, slot 0) lands before anything is read
+#pragma unroll
+  for (int pc = 0; pc < LPT; ++pc) issue_piece(K0{}, pc);
+  advance_load(K0{});
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  int c_k = 0;
+  bool epi_pending = false;
+
+  // one ring step of kind KIND (its slot), prefetching the following step (kind KIND^1) into the other slot
+  auto step = [&](auto kind_c) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    using KN = std::integral_constant<int, KIND ^ 1>;
+    // X tile 0 of this step, then per W tile i: the deferred MFMA of the previous step (old wf[i], X tile RM-1 in
+    // xf[1]) followed by the read of this step's W fragment INTO wf[i] — one W register set serves both steps
+    ld_frag(xf[0], kind_c, std::false_type{}, std::integral_constant<int, 0>{});
+    static_for<RN>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      if (c8_piece(-1, i, RN) >= 0) issue_piece(KN{}, c8_piece(-1, i, RN));
+      mma(KN{}, H0{}, acc[i][RM - 1], wf[i], xf[1]);      // (very first step: zero fragments)
+      mma(KN{}, H1{}, acc[i][RM - 1], wf[i], xf[1]);
+      ld_frag(wf[i], kind_c, std::true_type{}, ic);
+    });
+    if constexpr (KIND == 0) {
+      if (epi_pending) {
+        epilogue();
+        epi_pending = false;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // chunks j = 0 .. RM-2: issue the reads of X tile j+1, wait for everything older (tile j; in chunk 0 also the W
+    // fragments), then the MFMAs of tile j with the LDS-DMA pieces of the next step in between (c8_piece)
+    static_for<RM - 1>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      ld_frag(xf[(j + 1) & 1], kind_c, std::false_type{}, std::integral_constant<int, j + 1>{});
+      // all but the reads of the tile just requested: 2 LDS instructions per fp16 fragment, 4 per fp6 fragment
+      if constexpr (j == 0)
+        asm volatile("s_waitcnt lgkmcnt(%10)"
+                     : "+v"(xf[0].a), "+v"(xf[0].b), "+v"(wf[0].a), "+v"(wf[0].b), "+v"(wf[1].a), "+v"(wf[1].b),
+                       "+v"(wf[2].a), "+v"(wf[2].b), "+v"(wf[3].a), "+v"(wf[3].b)
+                     : "n"(KIND == 1 ? 4 : 2));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xf[j & 1].a), "+v"(xf[j & 1].b) : "n"(KIND == 1 ? 4 : 2));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < RN; ++i) {
+        constexpr int G = KIND == 1 ? RN : 2 * RN;
+        if (c8_piece(j, i, G) >= 0) issue_piece(KN{}, c8_piece(j, i, G));
+        mma(kind_c, H0{}, acc[i][j], wf[i], xf[j & 1]);
+      }
+      if constexpr (KIND == 0) {
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+          if (c8_piece(j, RN + i, 2 * RN) >= 0) issue_piece(KN{}, c8_piece(j, RN + i, 2 * RN));
+          mma(kind_c, H1{}, acc[i][j], wf[i], xf[j & 1]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    advance_load(KN{});
+    if (KIND == 1) {
+      if (++c_k == nk) { c_k = 0; epi_pending = true; }
+    }
+    // the next step must have landed; X tile RM-1 of this step (xf[1]) and wf[] are in registers
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[1].a), "+v"(xf[1].b) : : "memory");      // X tile RM-1 is in xf[1]
+    __builtin_amdgcn_s_barrier();
+  };
+
+#pragma unroll
+  for (int i = 0; i < RN; ++i) wf[i].a = wf[i].b = i4v_t{0, 0, 0, 0};
+  xf[1].a = xf[1].b = i4v_t{0, 0, 0, 0};
+  for (int c_step = 0; c_step < total; c_step += 2) {
+    step(K0{});
+    step(K1{});
+  }
+  // deferred tile of the last step (kind 1)
+#pragma unroll
+  for (int i = 0; i < RN; ++i) mma(K1{}, H0{}, acc[i][RM - 1], wf[i], xf[1]);
+  epilogue();
+}
+
+template <int EPI>
+void launch_cfg(const zk_gemm6_args& a6, hipStream_t s) {
+  constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144 + 8 * 512;
+  const zk_gemm_args& a = a6.a;
+  auto k = gemm_c6_kernel<EPI>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  const int ntiles = ((a.M + 255) / 256) * (a.N / 256);
+  const int grid = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a6);
+}
+
+}  // namespace
+
+// Host-side shape contract as zk_launch_gemm: N % 256 == 0, K % 64 == 0, M >= 1; x_lo / w_lo are c8 planes.
+void zk_launch_gemm_c6(const zk_gemm6_args& a, int epi, hipStream_t s) {
+  switch (epi) {
+    case ZK_EPI_STORE: launch_cfg<ZK_EPI_STORE>(a, s); break;
+    case ZK_EPI_GELU: launch_cfg<ZK_EPI_GELU>(a, s); break;
+    case ZK_EPI_RESID: launch_cfg<ZK_EPI_RESID>(a, s); break;
+    default: launch_cfg<ZK_EPI_PATCH>(a, s); break;
+  }
+}
