@@ -89,6 +89,18 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   const int my_tiles = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
   const int total = my_tiles * nk * 2;
   if (total == 0) return;
+#ifndef ZK_C8_STAGGER
+#define ZK_C8_STAGGER 12
+#endif
+  // RESID (O projection, FC2): de-phase the XCDs.  All tiles of a launch take the same time, so without this every CU
+  // reaches its epilogue — a burst of fp32 residual reads and writes, matrix pipe idle — at the same moment and the
+  // bursts queue at HBM.  XCD x starts x·nk·ZK_C8_STAGGER·64 cycles late (up to about half a tile time); the workgroups
+  // of one XCD stay in step (they share X panels through their L2).  Measured +2-5 % (O) / +4-6 % (FC2) at 28 tiles per
+  // workgroup; the store-only epilogues (QKV, FC1) lose 2-3 % with it and keep the common start, and launches of a few
+  // tiles per workgroup would only pay the late finish (17-window micro-batch: 0.7x), hence the tile-count guard.
+  if constexpr (EPI == ZK_EPI_RESID)
+    if (my_tiles >= 8)
+      for (int i = 0; i < xcd * nk; ++i) __builtin_amdgcn_s_sleep(ZK_C8_STAGGER);
 
   // ---- staging ----
   const int srow = lane / CPR, schunk = lane % CPR;
