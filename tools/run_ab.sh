@@ -1,6 +1,6 @@
 set -e
-AB_ONLY=o,fc2 timeout -k 10 300 python tools/gemm_ab.py 512 3 4 3 >> gpurun_out/sr.log 2>&1
-AB_ONLY=o,fc2 timeout -k 10 300 python tools/gemm_ab.py 256 3 4 3 >> gpurun_out/sr.log 2>&1
-AB_ONLY=o,fc2 timeout -k 10 300 python tools/gemm_ab.py 107 3 4 3 >> gpurun_out/sr.log 2>&1
-AB_ONLY=o,fc2 timeout -k 10 300 python tools/gemm_ab.py 17 3 4 3 >> gpurun_out/sr.log 2>&1
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm" > gpurun_out/sr_tests.log 2>&1
+Z=zenker-audio-detection_amd/zkast
+for v in ss2 ss5; do
+  echo "== $v" >> gpurun_out/ss.log
+  ZKAST_PROBES=$Z/libzkast_probes_$v.so AB_ONLY=qkv,fc1 timeout -k 10 300 python tools/gemm_ab.py 512 3 4 3 >> gpurun_out/ss.log 2>&1
+done

@@ -101,6 +101,11 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   if constexpr (EPI == ZK_EPI_RESID)
     if (my_tiles >= 8)
       for (int i = 0; i < xcd * nk; ++i) __builtin_amdgcn_s_sleep(ZK_C8_STAGGER);
+#ifdef ZK_C8_STAGGER_STORE      // probe: the same for the store-only epilogues
+  if constexpr (EPI == ZK_EPI_STORE || EPI == ZK_EPI_GELU)
+    if (my_tiles >= 8)
+      for (int i = 0; i < xcd * nk; ++i) __builtin_amdgcn_s_sleep(ZK_C8_STAGGER_STORE);
+#endif
 
   // ---- staging ----
   const int srow = lane / CPR, schunk = lane % CPR;
