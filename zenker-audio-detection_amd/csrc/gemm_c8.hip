@@ -313,45 +313,54 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
       // STORE (fused QKV): q keeps an fp16 lo plane (attention.hip rescales and re-splits it), k gets the c8 byte pairs
       // of the fp8-corrected QK^T (columns >= lo_c8_from), v has no lo plane (n >= lo_n_limit).
       // GELU (FC1 -> FC2 operand): the lo plane is the c8 byte pair.
-      const int LOFMT = (EPI == ZK_EPI_GELU || n0 >= a.lo_c8_from) ? ZK_LO_C8 : ZK_LO_F16;
-      const bool want_lo = a.o_lo != nullptr && n0 < a.lo_n_limit;
       [[maybe_unused]] const gelu_coef_t gk = gelu_coefficients();
+      // one specialised copy of the loop per lo format of the tile (compile-time LOFMT: -1 = no lo plane), picked by a
+      // wave-uniform branch per tile instead of a format test per element group
+      auto store_tile = [&](auto fmt_c) __attribute__((always_inline)) {
+        constexpr int LOFMT = decltype(fmt_c)::value;
 #pragma unroll
-      for (int j = 0; j < RM; ++j) {
-        h4_t lo4[RN];
-        const float sj = row_scale(j);
+        for (int j = 0; j < RM; ++j) {
+          [[maybe_unused]] h4_t lo4[RN];
+          const float sj = row_scale(j);
 #pragma unroll
-        for (int i = 0; i < RN; ++i) {
-          f4_t v = acc[i][j] * sj + b4[i];
-          acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
-          if constexpr (EPI == ZK_EPI_GELU) {
-            const gelu_f2_t g01 = gelu_erf2(gelu_f2_t{v[0], v[1]}, gk), g23 = gelu_erf2(gelu_f2_t{v[2], v[3]}, gk);
-            v[0] = g01[0]; v[1] = g01[1]; v[2] = g23[0]; v[3] = g23[1];
+          for (int i = 0; i < RN; ++i) {
+            f4_t v = acc[i][j] * sj + b4[i];
+            acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == ZK_EPI_GELU) {
+              const gelu_f2_t g01 = gelu_erf2(gelu_f2_t{v[0], v[1]}, gk), g23 = gelu_erf2(gelu_f2_t{v[2], v[3]}, gk);
+              v[0] = g01[0]; v[1] = g01[1]; v[2] = g23[0]; v[3] = g23[1];
+            }
+            h4_t hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hi[e] = (half_t)v[e];
+            if constexpr (LOFMT >= 0) {
+              const float vv[4] = {v[0], v[1], v[2], v[3]};
+              lo4[i] = zk_lo4(vv, hi, LOFMT);
+            }
+            *(h4_t*)(scr + frow * SCR_STR + i * 32 + fq * 8) = hi;
           }
-          h4_t hi;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) hi[e] = (half_t)v[e];
-          const float vv[4] = {v[0], v[1], v[2], v[3]};
-          lo4[i] = zk_lo4(vv, hi, LOFMT);
-          *(h4_t*)(scr + frow * SCR_STR + i * 32 + fq * 8) = hi;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
-          const int m = m0 + j * 16 + rd_row + 8 * t;
-          if (m < a.M) *(h8_t*)(a.o_hi + (size_t)m * a.N + n0 + rd_ch * 8) = v;
-        }
-        if (want_lo) {
-#pragma unroll
-          for (int i = 0; i < RN; ++i) *(h4_t*)(scr + frow * SCR_STR + i * 32 + fq * 8) = lo4[i];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
             const int m = m0 + j * 16 + rd_row + 8 * t;
-            if (m < a.M) *(h8_t*)(a.o_lo + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+            if (m < a.M) *(h8_t*)(a.o_hi + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+          }
+          if constexpr (LOFMT >= 0) {
+#pragma unroll
+            for (int i = 0; i < RN; ++i) *(h4_t*)(scr + frow * SCR_STR + i * 32 + fq * 8) = lo4[i];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
+              const int m = m0 + j * 16 + rd_row + 8 * t;
+              if (m < a.M) *(h8_t*)(a.o_lo + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+            }
           }
         }
-      }
+      };
+      const bool want_lo = a.o_lo != nullptr && n0 < a.lo_n_limit;
+      if (!want_lo) store_tile(std::integral_constant<int, -1>{});
+      else if (EPI == ZK_EPI_GELU || n0 >= a.lo_c8_from) store_tile(std::integral_constant<int, ZK_LO_C8>{});
+      else if constexpr (EPI != ZK_EPI_GELU) store_tile(std::integral_constant<int, ZK_LO_F16>{});
     }
     ++c_ord; c_tile += stride;
   };
