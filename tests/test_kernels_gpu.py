@@ -265,6 +265,7 @@ def test_gemm_c8_exact_integers_many_shapes(ctx):
     for _ in range(19):
         shapes.append((int(rng.integers(1, 3000)), int(rng.choice([768, 2304, 3072])), int(rng.choice([256, 768, 3072]))))
     shapes.append((70000, 768, 768))                     # > 256 tiles per column block: several rounds per workgroup
+    shapes.append((180000, 768, 256))                    # >= 8 tiles per workgroup: the RESID launch staggers its XCDs
     for (M, N, K) in shapes:
         x = rng.integers(-2, 3, (M, K)).astype(np.float32)
         w = rng.integers(-2, 3, (N, K)).astype(np.float32)

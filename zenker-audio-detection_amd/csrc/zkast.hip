@@ -1016,7 +1016,7 @@ int zk_test_layernorm(zk_ctx* c, const float* x, const float* gamma, const float
   float *dx, *dg, *db; half_t *hi, *lo; int32_t* dexp;
   HIPCHK(c, hipMalloc((void**)&dx, n * 4)); HIPCHK(c, hipMalloc((void**)&dg, ZK_HIDDEN * 4)); HIPCHK(c, hipMalloc((void**)&db, ZK_HIDDEN * 4));
   HIPCHK(c, hipMalloc((void**)&hi, n * 2)); HIPCHK(c, hipMalloc((void**)&lo, n * 2));
-  HIPCHK(c, hipMalloc((void**)&dexp, (size_t)rows * 4)); HIPCHK(c, hipMemset(dexp, 0, (size_t)rows * 4));
+  HIPCHK(c, hipMalloc((void**)&dexp, (size_t)rows * 4)); HIPCHK(c, hipMemsetAsync(dexp, 0, (size_t)rows * 4, c->stream));
   HIPCHK(c, hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dg, gamma, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(db, beta, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
@@ -1063,7 +1063,9 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   // in that clamp from faulting)
   const size_t nxp = nx + (size_t)256 * K;
   HIPCHK(c, hipMalloc((void**)&xh, nxp * 2)); HIPCHK(c, hipMalloc((void**)&xl, nxp * 2));
-  HIPCHK(c, hipMemset(xh, 0, nxp * 2)); HIPCHK(c, hipMemset(xl, 0, nxp * 2));
+  // (memsets go on the context's stream: a plain hipMemset runs on the NULL stream, which the non-blocking context stream
+  // does not wait for — it could land after the kernels below had written the buffer)
+  HIPCHK(c, hipMemsetAsync(xh, 0, nxp * 2, c->stream)); HIPCHK(c, hipMemsetAsync(xl, 0, nxp * 2, c->stream));
   HIPCHK(c, hipMalloc((void**)&wh, nw * 2)); HIPCHK(c, hipMalloc((void**)&wl, nw * 2));
   HIPCHK(c, hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dw, w, nw * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice));
@@ -1072,7 +1074,7 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   int w_exp = 0;
   if (nsplit == ZK_F16C8) {      // lo planes become c8 byte pairs
     w_exp = c8_exponent(w, nw);
-    HIPCHK(c, hipMalloc((void**)&dexp, (size_t)(M + 256) * 4)); HIPCHK(c, hipMemset(dexp, 0, (size_t)(M + 256) * 4));
+    HIPCHK(c, hipMalloc((void**)&dexp, (size_t)(M + 256) * 4)); HIPCHK(c, hipMemsetAsync(dexp, 0, (size_t)(M + 256) * 4, c->stream));
     zk_launch_split_rows_c8(dx, M, K, xh, xl, dexp, c->stream);      // row-scaled planes, as LayerNorm writes them
     zk_launch_split_c8(dw, (int64_t)nw, w_exp, 1, wl, c->stream);
   }
@@ -1082,7 +1084,7 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
     if (epi == ZK_EPI_PATCH) { HIPCHK(c, hipMalloc((void**)&dpos, (size_t)ZK_SEQ * N * 4)); HIPCHK(c, hipMemcpy(dpos, pos, (size_t)ZK_SEQ * N * 4, hipMemcpyHostToDevice)); }
   } else {
     HIPCHK(c, hipMalloc((void**)&oh, no * 2)); HIPCHK(c, hipMalloc((void**)&ol, no * 2));
-    HIPCHK(c, hipMemset(ol, 0, no * 2));
+    HIPCHK(c, hipMemsetAsync(ol, 0, no * 2, c->stream));
   }
   zk_gemm_args a;
   a.x_hi = xh; a.x_lo = nsplit != ZK_F16 ? xl : nullptr; a.w_hi = wh; a.w_lo = nsplit != ZK_F16 ? wl : nullptr; a.bias = dbias;
@@ -1119,7 +1121,7 @@ int zk_test_attention(zk_ctx* c, const float* qkv, int32_t W, int32_t nsplit, fl
   float* dq; half_t *qh, *ql, *oh, *ol;
   HIPCHK(c, hipMalloc((void**)&dq, nq * 4)); HIPCHK(c, hipMalloc((void**)&qh, nq * 2)); HIPCHK(c, hipMalloc((void**)&ql, nq * 2));
   HIPCHK(c, hipMalloc((void**)&oh, no * 2)); HIPCHK(c, hipMalloc((void**)&ol, no * 2));
-  HIPCHK(c, hipMemset(ol, 0, no * 2));
+  HIPCHK(c, hipMemsetAsync(ol, 0, no * 2, c->stream));
   HIPCHK(c, hipMemcpy(dq, qkv, nq * 4, hipMemcpyHostToDevice));
   zk_launch_split_f32(dq, (int64_t)nq, 1.f, qh, ql, c->stream);
   const int lf = nsplit == ZK_F16C8 ? ZK_LO_C8 : ZK_LO_F16;
