@@ -16,6 +16,9 @@
  *  - return value 0 = ok, negative = error (ZK_E_*); no exceptions or aborts cross the boundary.
  *  - a context is bound to one GPU and one HIP stream and is NOT thread-safe; calls are synchronous on return
  *    unless the context was switched to async mode with zk_set_async(ctx, 1) (then call zk_synchronize()).
+ *    The context's own stream is NON-BLOCKING: it does not wait for work queued on the NULL stream or on another
+ *    library's stream.  Device buffers handed in must be complete (synchronize their producer), or the producer's
+ *    stream must be given to the context with zk_set_stream().
  */
 #ifndef ZKAST_H
 #define ZKAST_H
