@@ -10,7 +10,9 @@
 //    directly the B operand of  Oᵀ[d][q] += Vᵀ·Pᵀ  (no LDS round trip for P).
 //  * K tile [64 keys][64 d] in LDS, 16-B chunk swizzle (key>>1)&7 (conflict-free ds_read_b128 for the 32x32x16
 //    A-operand pattern); V tile [64 keys][64 d] read TRANSPOSED with ds_read_b64_tr_b16, swizzle ((key>>1)&1)<<2.
-//  * K/V tiles are prefetched global->VGPR during the MFMA phase and written to the other LDS buffer after it.
+//  * K/V tiles arrive by LDS-DMA (global_load_lds_dwordx4, swizzles applied on the source side) into 3-deep rings; the
+//    loop is a sequence of fenced slots — one MFMA group, the fragment reads of the slot four ahead, a share of the
+//    vector work — with K running one tile ahead of V (see "one key tile as a sequence of SLOTS" below).
 //  * NSPLIT=3: q and k are (hi, lo) fp16 pairs, Sᵀ += Kh·Qh + Kl·Qh + Kh·Ql (the scores feed exp(), which
 //    amplifies operand rounding); P·V stays single-pass (measured contribution 8e-5 on the logits).
 //  * NSPLIT=2 (ZK_F16C8): the two correction products ride ONE fp8 pass as in gemm_c8.hip: k's lo plane holds the c8
@@ -32,7 +34,7 @@ namespace {
 #define ZK_ATT_DMA_TOP 0      // 1: all staging pieces at the top of the iteration instead of between the MFMA slots
 #endif
 #ifndef ZK_ATT_ABL
-#define ZK_ATT_ABL 0      // probe builds only: 1 no K/V staging, 2 no barrier, 4 no exponentials
+#define ZK_ATT_ABL 0      // probe builds only (timing, wrong results): 1 no K/V staging, 2 no barrier, 4 no exponentials, 8 half the staging
 #endif
 typedef int i2v_t __attribute__((ext_vector_type(2)));
 typedef int i4v_t __attribute__((ext_vector_type(4)));
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   float m_run = 0.f, l_run = 0.f;
 
   // ---- one key tile as a sequence of SLOTS ----
-  // A slot = the LDS fragment reads of the slot two ahead, one group of MFMAs, and a share of the VALU work, fenced by
+  // A slot = the LDS fragment reads of the slot LA (= 4) ahead, one group of MFMAs, and a share of the VALU work, fenced by
   // sched_barrier so that hipcc keeps the interleave (left alone it runs the MFMAs back to back, each behind its own
   // LDS round trip, and the softmax after them).
   //   score slots (tile t+1):  C8: per 32-key block 2 fp8 groups (1 MFMA, 64 cycles, 4 exps) + 4 fp16 groups (1 MFMA,
