@@ -54,14 +54,17 @@ constexpr int S_ = ZK_SEQ;
 constexpr int QKV_LD = 3 * ZK_HIDDEN;   // 2304
 constexpr int KT = 64;                  // keys per tile
 constexpr int NKT = (S_ + KT - 1) / KT; // 19
-constexpr int QT = 128;                 // query rows per workgroup
-constexpr int NQT = (S_ + QT - 1) / QT; // 10
+#ifndef ZK_ATT_NW
+#define ZK_ATT_NW 4      // waves per workgroup (4: two workgroups per CU; 8: one, half the K/V staging per wave)
+#endif
+constexpr int NW = ZK_ATT_NW;
+constexpr int QT = 32 * NW;             // query rows per workgroup
 constexpr int TILE_B = KT * 128;        // bytes of one [64][64] fp16 image
 
 template <int NSPLIT>
-__global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict__ qkv_hi,
+__global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __restrict__ qkv_hi,
                                                         const half_t* __restrict__ qkv_lo, half_t* __restrict__ o_hi,
-                                                        half_t* __restrict__ o_lo, int n_windows, int q_tiles, int lo_fmt) {
+                                                        half_t* __restrict__ o_lo, int n_windows, int q_tiles, int lo_fmt, int row_limit) {
   constexpr bool SPLIT = (NSPLIT >= 2);
   constexpr bool C8 = (NSPLIT == 2);
   constexpr int NIMG = SPLIT ? 3 : 2;     // Kh, [Kl | Kc8], V
@@ -125,11 +128,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   // lane&7); the XOR swizzles of the images are applied on the SOURCE side (the DMA writes LDS lane-linearly).
   // A 64-key image has 8 pieces: wave w issues pieces w and w+4 (rows +32: same swizzle term).
   constexpr int NKIMG = NIMG - 1;     // K images (Kh, [Kl | Kc8])
-  constexpr int PER_ITER = 2 * NIMG;  // DMA instructions per wave and iteration
-  unsigned koff[2], voff[2], koff_last[2], voff_last[2];
+  constexpr int PPI = 8 / NW;             // pieces per image and wave: row blocks wave, wave + NW, ...
+  constexpr int PER_ITER = PPI * NIMG;    // DMA instructions per wave and iteration
+  unsigned koff[PPI], voff[PPI], koff_last[PPI], voff_last[PPI];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int row = (wave + 4 * u) * 8 + (lane >> 3), cl = lane & 7;
+  for (int u = 0; u < PPI; ++u) {
+    const int row = (wave + NW * u) * 8 + (lane >> 3), cl = lane & 7;
     const unsigned kc = (unsigned)((cl ^ ((row >> 1) & 7)) << 4), vc = (unsigned)((cl ^ (((row >> 1) & 1) << 2)) << 4);
     koff[u] = (unsigned)row * (unsigned)(QKV_LD * 2) + kc;
     voff[u] = (unsigned)row * (unsigned)(QKV_LD * 2) + vc;
@@ -156,16 +160,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   // V image of tile kt_v -> V slot sv.  Tiles are clamped to the last one: the surplus fetches of the final iterations
   // land in dead slots.
   auto dma_piece = [&](int pc, int kt_k, int sk, int kt_v, int sv) __attribute__((always_inline)) {
-    const bool isk = pc < 2 * NKIMG;
+    const bool isk = pc < PPI * NKIMG;
     int kt = isk ? kt_k : kt_v;
     kt = kt < NKT - 1 ? kt : NKT - 1;
     const bool last = kt == NKT - 1;
-    const int u = pc & 1, img = isk ? pc >> 1 : 0;
+    const int u = pc % PPI, img = isk ? pc / PPI : 0;
     const size_t tb = ((tok0 + (size_t)kt * KT) * QKV_LD + head * ZK_HEAD_DIM) * 2;     // bytes
     const char* src = (img == 1 ? (const char*)qkv_lo : (const char*)qkv_hi) + tb + (isk ? 1 : 2) * ZK_HIDDEN * 2;
     char* base = isk ? smem + sk * KBUF_B + img * TILE_B : smem + V_OFF + sv * TILE_B;
     const unsigned o = isk ? (last ? koff_last[u] : koff[u]) : (last ? voff_last[u] : voff[u]);
-    dma(uniform_ptr(src), o, base + (wave + 4 * u) * 1024);
+    dma(uniform_ptr(src), o, base + (wave + NW * u) * 1024);
   };
 
   // ---- per-lane LDS read offsets ----
@@ -299,12 +303,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
 
   // a wave whose 32 query rows all lie beyond the sequence (the last query tile holds 62 of 128 rows: waves 2 and 3)
   // only takes part in the K/V staging and the barriers — its SIMD time goes to the other resident workgroup
-  const bool wave_active = __builtin_amdgcn_readfirstlane(qt * QT + wave * 32) < S_;
+  const bool wave_active = __builtin_amdgcn_readfirstlane(qt * QT + wave * 32) < (row_limit < S_ ? row_limit : S_);
 #pragma unroll
   for (int pc = 0; pc < PER_ITER; ++pc) {
     dma_piece(pc, 0, 0, 0, 0);
     dma_piece(pc, 1, 1, 1, 1);
-    if (pc < 2 * NKIMG) dma_piece(pc, 2, 2, 0, 0);
+    if (pc < PPI * NKIMG) dma_piece(pc, 2, 2, 0, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
   // ---- finalize: O / l, store 4 consecutive d per register group ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
-  if (q_row < S_) {
+  if (q_row < S_ && wave_active) {
     const size_t obase = (tok0 + q_row) * ZK_HIDDEN + head * ZK_HEAD_DIM;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -481,15 +485,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
 
 void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit, int q_tiles, hipStream_t s) {
   if (n_windows <= 0) return;
-  if (q_tiles <= 0 || q_tiles > NQT) q_tiles = NQT;   // q_tiles < 10: only the first q_tiles*128 query rows (last-layer pruning)
-  const int grid = q_tiles * ZK_HEADS * n_windows;
+  // q_tiles counts 128-row query blocks (< 10: only the first q_tiles*128 query rows, the last layer's pruning); the
+  // kernel's workgroup covers QT = 32·NW rows, waves beyond the row limit only help staging
+  if (q_tiles <= 0 || q_tiles > 10) q_tiles = 10;
+  const int row_limit = q_tiles * 128;
+  const int wg_tiles = (row_limit < S_ ? row_limit + QT - 1 : S_ + QT - 1) / QT;
+  const int grid = wg_tiles * ZK_HEADS * n_windows;
   auto go = [&](auto kernel, int lds) {
     static bool attr[4] = {false, false, false, false};      // (the 3-deep rings of the split kernels exceed the 64 KiB default)
     if (!attr[nsplit & 3]) {
       (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr[nsplit & 3] = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, q_tiles, out.lo_fmt);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * NW), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, wg_tiles, out.lo_fmt, row_limit);
   };
   if (nsplit == 2) go(attention_kernel<2>, 3 * 3 * TILE_B);
   else if (nsplit == 3) go(attention_kernel<3>, 3 * 3 * TILE_B);
