@@ -35,6 +35,7 @@ SCHEME = "x3"
 import os
 QK = os.environ.get("QK", "x3")      # attention score product: x3 (3 fp16 passes) | c8 | f16
 STAT = {}
+DROP = os.environ.get("DROP_XLO", "")      # "fc2": FC2's X-side correction term dropped (GELU output as fp16 + fp8(x) only)
 def lin(x, w, b, quant):
     x = np.asarray(x, np.float32); w = np.asarray(w, np.float32)
     xh = f16(x); xl = f16(x - xh); wh = f16(w); wl = f16(w - wh)
@@ -54,6 +55,7 @@ def lin(x, w, b, quant):
         x8 = fp8(x * 2.0**c, kind); xl8 = fp8((x - xh) * 2.0**d, kind)
         w8 = fp8(w * 2.0**a, kind); wl8 = fp8((w - wh) * 2.0**bb, kind)
         STAT["xsat"] = max(STAT.get("xsat", 0), float(np.abs(x * 2.0**c).max()))
+        if DROP == "fc2" and w.shape[1] == 3072: xl8 = xl8 * 0
         corr = (xl8 @ w8.T + x8 @ wl8.T) * np.float32(2.0 ** -(a + d))
         return xh @ wh.T + corr + b
     if SCHEME.startswith("fp6"):
