@@ -1,7 +1,3 @@
+# scratch: the command list of the last A/B run on the GPU box (gpurun -- 'bash tools/run_ab.sh'); edit freely
 set -e
-Z=zenker-audio-detection_amd/zkast
-timeout -k 10 300 python tools/attn_ab.py 512 > gpurun_out/nw.log 2>&1
-timeout -k 10 500 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "attention" > gpurun_out/nw_tests.log 2>&1
-echo "== nw8" >> gpurun_out/nw.log
-ZKAST_PROBES=$Z/libzkast_probes_nw8.so timeout -k 10 300 python tools/attn_ab.py 512 >> gpurun_out/nw.log 2>&1
-ZKAST_LIB=$Z/libzkast_nw8.so timeout -k 10 500 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "attention" >> gpurun_out/nw_tests.log 2>&1
+timeout -k 10 300 python tools/gemm_ab.py 512 3 4 3 > gpurun_out/ab.log 2>&1
