@@ -1,3 +1,3 @@
-# scratch: the command list of the last A/B run on the GPU box (gpurun -- 'bash tools/run_ab.sh'); edit freely
 set -e
-timeout -k 10 300 python tools/gemm_ab.py 512 3 4 3 > gpurun_out/ab.log 2>&1
+Z=zenker-audio-detection_amd/zkast
+ZKAST_PROBES=$Z/libzkast_probes_nt.so timeout -k 10 300 python tools/gemm_ab.py 512 3 4 3 > gpurun_out/nt.log 2>&1
