@@ -1,4 +1,3 @@
+# scratch: the command list of the last A/B run on the GPU box (gpurun -- 'bash tools/run_ab.sh'); edit freely
 set -e
-Z=zenker-audio-detection_amd/zkast
-ZKAST_LIB=$Z/libzkast_lnr.so timeout -k 10 500 python bench.py --headline-only --steps 4 --warmup 2 > gpurun_out/lnr.log 2>&1
-timeout -k 10 500 python bench.py --headline-only --steps 4 --warmup 2 > gpurun_out/lnr_base.log 2>&1
+timeout -k 10 300 python tools/gemm_ab.py 512 3 4 3 > gpurun_out/ab.log 2>&1
