@@ -345,7 +345,11 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
             const int m = m0 + j * 16 + rd_row + 8 * t;
             // (non-temporal: the planes are read by the NEXT kernel from their first row on, long after these lines would have
             // left the caches; kept out of L2 they stop evicting the W / X lines of the k-loops: FC1 +2 %, QKV +0.7 %)
+#ifdef ZK_C8_NO_NT      // probe builds: plain stores
+            if (m < a.M) *(h8_t*)(a.o_hi + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+#else
             if (m < a.M) __builtin_nontemporal_store(v, (h8_t*)(a.o_hi + (size_t)m * a.N + n0 + rd_ch * 8));
+#endif
           }
           if constexpr (LOFMT >= 0) {
 #pragma unroll
@@ -354,7 +358,11 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
             for (int t = 0; t < 2; ++t) {
               const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
               const int m = m0 + j * 16 + rd_row + 8 * t;
+#ifdef ZK_C8_NO_NT
+              if (m < a.M) *(h8_t*)(a.o_lo + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+#else
               if (m < a.M) __builtin_nontemporal_store(v, (h8_t*)(a.o_lo + (size_t)m * a.N + n0 + rd_ch * 8));
+#endif
             }
           }
         }
