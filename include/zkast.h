@@ -94,6 +94,12 @@ int zk_features_expand(zk_ctx* ctx, float mean, float std, int32_t do_normalize,
 /* copy the compact slot out: (n_windows, n_frames, 128) fp32 */
 int zk_features_get(zk_ctx* ctx, float* out /*host|device*/, int32_t* n_windows, int32_t* n_frames);
 
+/* the inverse: put compact un-normalised log-mel features (n_windows, n_frames, 128) fp32 host|device into the slot, as
+ * if zk_logmel had just produced them.  Replaces re-running the extractor when a feature cache exists
+ * (src/test_long_audio_windows_2stage_cache.py:163-168 loads a (N,1024,128) bundle; the compact store keeps only the
+ * n_frames real rows, and each stage applies its own mean/std when it reads the slot).                              */
+int zk_features_set(zk_ctx* ctx, const float* feats /*host|device*/, int32_t n_windows, int32_t n_frames);
+
 /* ---- transformer -------------------------------------------------------------------------------------------- */
 /* replaces ASTForAudioClassification.forward: input_values (B,1024,128) fp32 host|device -> logits (B,labels).
  * input_values == NULL: run on the feature slot (normalised with the stage's mean/std); win_idx (host|device,

@@ -279,3 +279,85 @@ def test_evaluate_host_helpers(tmp_path):
     assert y_pred.tolist() == [0, 1, 0] and cm.tolist() == [[1, 0], [1, 1]]
     p = ev.softmax(np.array([[0.0, 0.0], [1.0, 3.0]], np.float32))
     assert np.allclose(p.sum(1), 1.0) and abs(p[1, 1] - 1 / (1 + np.exp(-2.0))) < 1e-6
+
+
+def _fake_logmel(n, nf=98, seed=0):
+    rng = np.random.default_rng(seed)
+    return (rng.normal(-6.0, 3.0, size=(n, nf, 128))).astype(np.float32)
+
+
+def test_compact_store_roundtrip_and_reference_bundle_interop(tmp_path):
+    """compact (N,98,128) store <-> the reference's (N,1024,128) `.pt` bundle.  The bundle written here has
+    the reference's keys / metadata (..._cache.py:106-124,181-187) and is accepted back; a store written in this
+    build's own format round-trips bit for bit; a foreign or stale entry is ignored, never trusted."""
+    import torch
+    from zkast import cache
+    fx = ZkASTFeatureExtractor(mean=-1.1509622, std=3.5340312)
+    wav = tmp_path / "p006_long.wav"
+    pl.write_wav_pcm16(str(wav), np.zeros(16000 + 5 * 8000, np.float32), 16000)
+    feats = cache.CompactFeatures(_fake_logmel(6), {"note": "unit test"})
+    assert cache.n_frames_of(1.0) == 98 and len(feats) == 6 and feats.n_frames == 98
+    # expand == HF semantics: zero pad to 1024 rows, then (x - mean) / (2 std) everywhere
+    ex = feats.expand(fx)
+    assert ex.shape == (6, 1024, 128) and ex.dtype == np.float32
+    assert np.array_equal(ex[:, :98], (feats.logmel - np.float32(fx.mean)) / np.float32(2 * fx.std))
+    assert np.all(ex[:, 98:] == np.float32(-np.float32(fx.mean)) / np.float32(2 * fx.std))
+    raw_fx = ZkASTFeatureExtractor(do_normalize=False)
+    assert np.array_equal(feats.expand(raw_fx)[:, :98], feats.logmel) and not feats.expand(raw_fx)[:, 98:].any()
+    # inverse: within one ulp of the log-mel value
+    back = cache.CompactFeatures.from_expanded(ex, fx, 98)
+    assert np.abs(back.logmel - feats.logmel).max() <= 2e-6
+    # own format
+    logs = []
+    store = cache.FeatureCache(str(tmp_path / "c"), log=logs.append)
+    key = cache.EntryKey.of(str(wav), 1.0, 0.5, 16000, cache.get_fx_fingerprint(fx))
+    assert store.lookup(key, 6, fx) is None
+    store.store(key, feats, fx)
+    compact_path, bundle_path = store._paths(key)
+    assert os.path.exists(compact_path) and os.path.exists(bundle_path)
+    assert bundle_path == cache.build_cache_path(str(tmp_path / "c"), str(wav), 1.0, 0.5, 16000, key.fingerprint)
+    assert os.path.getsize(compact_path) * 9 < os.path.getsize(bundle_path)
+    got = store.lookup(key, 6, fx)
+    assert np.array_equal(got.logmel, feats.logmel) and got.provenance == {"note": "unit test"}
+    # the `.pt` twin is exactly what the reference writes and reads
+    bundle = torch.load(bundle_path)
+    assert set(bundle) == {"metadata", "features"} and tuple(bundle["features"].shape) == (6, 1024, 128)
+    want = cache.build_base_metadata(str(wav), 1.0, 0.5, 6, 16000, key.fingerprint)
+    assert {k: bundle["metadata"][k] for k in want} == want and bundle["metadata"]["feature_shape"] == [6, 1024, 128]
+    assert np.array_equal(bundle["features"].numpy(), ex)
+    # only the reference bundle present -> imported and compacted
+    os.remove(compact_path)
+    imp = store.lookup(key, 6, fx)
+    assert imp is not None and np.abs(imp.logmel - feats.logmel).max() <= 2e-6 and "imported_from" in imp.provenance
+    # another window count / a touched file / a corrupt entry -> not used
+    assert store.lookup(key, 7, fx) is None
+    open(compact_path, "wb").write(b"not an npz")
+    os.remove(bundle_path)
+    assert store.lookup(key, 6, fx) is None and any("cannot use" in l for l in logs)
+    other = cache.EntryKey.of(str(wav), 1.0, 0.25, 16000, key.fingerprint)
+    assert other.digest != key.digest and store.lookup(other, 6, fx) is None
+    with pytest.raises(ValueError):
+        cache.CompactFeatures(np.zeros((2, 98, 64), np.float32))
+
+
+def test_entry_key_digest_is_the_reference_key_string(tmp_path):
+    """digest = sha256("<abs>|<win>|<hop>|<sr>|<fingerprint>|<size>_<mtime>")[:16] (..._cache.py:97-100)."""
+    import hashlib
+    from zkast import cache
+    wav = tmp_path / "a b.wav"
+    pl.write_wav_pcm16(str(wav), np.zeros(100, np.float32), 16000)
+    key = cache.EntryKey.of(str(wav), 1.0, 0.5, 16000, "f" * 64)
+    st_ = os.stat(wav)
+    text = f"{os.path.abspath(wav)}|1.0|0.5|16000|{'f' * 64}|{st_.st_size}_{int(st_.st_mtime)}"
+    assert key.digest == hashlib.sha256(text.encode()).hexdigest()[:16] and key.stem == "a b_" + key.digest
+
+
+def test_window_audio_views_equal_the_oracle_windows():
+    rng = np.random.default_rng(3)
+    for T, w, h in [(40000, 1.0, 0.5), (16000, 1.0, 0.5), (5000, 1.0, 0.5), (16001, 1.0, 0.5), (80000, 1.0, 1.5),
+                    (16000, 0.25, 0.1)]:
+        a = rng.standard_normal(T).astype(np.float32)
+        got, ref = pl.window_audio(a, w, h), orc.window_audio(a, w, h)
+        assert len(got) == len(ref) and all(np.array_equal(g, r) for g, r in zip(got, ref))
+    full = pl.window_audio(np.arange(40000, dtype=np.float32), 1.0, 0.5)
+    assert full[1].base is not None and full[1][0] == 8000.0          # strided view, not a copy

@@ -271,6 +271,42 @@ def test_feature_cache_roundtrip_and_probs_from_features(tmp_path):
     assert cache.forward_probs_from_features(model, f2[:0], 4).shape == (0, 0)
 
 
+def test_compact_cache_feeds_both_stages_by_affine_renormalisation(tmp_path):
+    """ONE compact (N,98,128) store serves both stages although their extractors differ in mean/std — the
+    store goes to the device slot once (zk_features_set) and each stage normalises it with its own statistics.  The
+    reference can only re-use features when both extractors are identical (..._cache.py:418-422).  Checked against the
+    uncached path (fresh log-mel per stage) bit for bit, and against a bundle imported from the reference format."""
+    from zkast import ZkASTFeatureExtractor, cache, forward_probs, pipeline, synth
+    m1, _ = _model(12, "init", 0)
+    m2, _ = _model(13, "wide", 1, mean=-6.5, std=2.75)
+    fx1 = ZkASTFeatureExtractor(mean=-1.1509622, std=3.5340312)
+    fx2 = ZkASTFeatureExtractor(mean=-6.5, std=2.75)
+    rec = synth.synth_recording(33, 16000 + 6 * 8000)
+    wav = str(tmp_path / "rec.wav")
+    pipeline.write_wav_pcm16(wav, rec, 16000)
+    audio = pipeline.load_audio(wav)
+    wins = pipeline.window_audio(audio, 1.0, 0.5)
+    logs = []
+    store = cache.load_or_compute_features(wav, wins, fx1, 1.0, 0.5, 4, str(tmp_path / "c"), log=logs.append, compact=True)
+    assert isinstance(store, cache.CompactFeatures) and store.logmel.shape == (7, 98, 128)
+    again = cache.load_or_compute_features(wav, wins, fx1, 1.0, 0.5, 4, str(tmp_path / "c"), log=logs.append, compact=True)
+    assert np.array_equal(again.logmel, store.logmel) and any(".zkc.npz" in l and "Loaded" in l for l in logs)
+    m1.bind_feature_extractor(fx1)
+    m2.bind_feature_extractor(fx2)
+    p1 = cache.forward_probs_from_features(m1, again, 4)
+    p2 = cache.forward_probs_from_features(m2, again, 4)
+    assert np.array_equal(p1, forward_probs(m1, fx1, wins, 7)) and np.array_equal(p2, forward_probs(m2, fx2, wins, 7))
+    # the reference-format twin, imported: the de-normalisation round trip moves log-mel by <= 1 ulp -> same probabilities
+    # to well inside the logit tolerance
+    key = cache.EntryKey.of(wav, 1.0, 0.5, 16000, cache.get_fx_fingerprint(fx1))
+    fc = cache.FeatureCache(str(tmp_path / "c"), log=logs.append)
+    os.remove(fc._paths(key)[0])
+    imported = fc.lookup(key, 7, fx1)
+    assert imported is not None and np.abs(imported.logmel - store.logmel).max() <= 2e-6
+    assert np.abs(cache.forward_probs_from_features(m2, imported, 4) - p2).max() <= 1e-5
+    assert cache.forward_probs_from_features(m1, cache.CompactFeatures(store.logmel[:0]), 4).shape == (0, 0)
+
+
 @pytest.mark.parametrize("window_sec,hop_sec,n_samples", [(2.0, 1.0, 16000 * 5), (0.5, 0.25, 16000), (1.0, 0.5, 9000),
                                                            (11.0, 11.0, 16000 * 11)])
 def test_other_window_geometries_vs_oracle(window_sec, hop_sec, n_samples):

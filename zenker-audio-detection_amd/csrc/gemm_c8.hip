@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   constexpr int SCR_STR = 144, SCR_WAVE = 16 * SCR_STR;
   constexpr int RSC_OFF = SCR_OFF + 8 * SCR_WAVE;      // per wave: 128 row scales (fp32) of its X rows, epilogue only
   constexpr int TILE_B = 16 * ROWB;               // 2048 B between consecutive 16-row tiles
+  constexpr int PF_OFF = RSC_OFF + 8 * 512;       // 256 B per wave: landing strip of the L2-prefetch dwords (never read)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -92,6 +93,9 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 #ifndef ZK_C8_STAGGER
 #define ZK_C8_STAGGER 12
 #endif
+#ifndef ZK_C8_PF
+#define ZK_C8_PF 0      // L2 prefetch distance of the X panel in ring steps past the load cursor (0 = off)
+#endif
   // RESID (O projection, FC2): de-phase the XCDs.  All tiles of a launch take the same time, so without this every CU
   // reaches its epilogue — a burst of fp32 residual reads and writes, matrix pipe idle — at the same moment and the
   // bursts queue at HBM.  XCD x starts x·nk·ZK_C8_STAGGER·64 cycles late (up to about half a tile time); the workgroups
@@ -111,24 +115,28 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   const int srow = lane / CPR, schunk = lane % CPR;
   int l_step = 0, l_k = 0, l_ord = 0, l_tile = first;
   int l_m0 = (first / tiles_n) * BM, l_n0 = (first % tiles_n) * BN;
-  unsigned xoffs[XI], woffs[WI];
-  auto set_xoffs = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < XI; ++q) {
-      const int row = (q * 8 + wave) * RPI + srow;
-      int grow = l_m0 + row;
-      grow = grow < a.M ? grow : a.M - 1;
-      const int c = schunk ^ ((row >> 1) & (CPR - 1));
-      xoffs[q] = (unsigned)(grow - l_m0) * (unsigned)(a.K * 2) + (unsigned)(c * 16);
-    }
-  };
-#pragma unroll
-  for (int q = 0; q < WI; ++q) {
-    const int row = (q * 8 + wave) * RPI + srow;
+  // ONE per-lane offset serves every piece: piece q of either operand covers rows q·64 + wave·8 + srow of the tile, and
+  // the swizzled chunk ((row >> 1) & 7 does not depend on q), so q moves into the wave-uniform base address.  (Rows >= M
+  // of the last row block are read as they lie — the planes hold whole 256-row tiles, zk_gemm_args — and never stored.)
+  unsigned poff;
+  {
+    const int row = wave * RPI + srow;
     const int c = schunk ^ ((row >> 1) & (CPR - 1));
-    woffs[q] = (unsigned)row * (unsigned)(a.K * 2) + (unsigned)(c * 16);
+    poff = (unsigned)row * (unsigned)(a.K * 2) + (unsigned)(c * 16);
   }
-  set_xoffs();
+#if ZK_C8_PF
+  // ---- cooperative L2 prefetch of the X panel (see pf_issue) ----
+  // The X lines of a ring step are new to every cache: all tiles_n column-tile workgroups of a row block ask for them at
+  // the same moment, one HBM fetch with the others queued behind it, and with one 64-KiB step in flight per CU the fill
+  // stream is bound by that round trip (fill probe: 65 GB/s per CU with X from HBM, 93 with X L2-resident).  So the
+  // workgroups of a row block share the job of touching each X line ONCE, ZK_C8_PF steps ahead of the load cursor: the
+  // workgroup of column tile tn touches rows [tn·pf_rows, (tn+1)·pf_rows) of the step's 256 — one 4-byte LDS-DMA per
+  // lane and line, issued by wave 7 (and wave 6 when pf_rows > 64) as the FIRST vector-memory instruction of a step, so
+  // that it has the whole step to land before the step's closing vmcnt(0).
+  const int pf_rows = (BM + tiles_n - 1) / tiles_n;
+  const int pf_waves = (pf_rows + 63) >> 6;      // 1 (QKV, FC1) or 2 (O, FC2: 86 rows)
+  const bool pf_wave = wave >= 8 - pf_waves;
+#endif
   // piece `pc` of the step at the load cursor; KIND (0 = fp16 planes -> slot 0, 1 = c8 planes -> slot 1) is static.
   // Pieces are UNCONDITIONAL so that a ring step is one basic block (hipcc otherwise sinks the MFMAs of a step below
   // all of its memory instructions): once the cursor has run past the last step it stays on it and the pieces
@@ -141,20 +149,23 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
     const int k0 = l_k * BK;
     if (pc < XI) {
       const int instr = pc * 8 + wave;
-      const char* gb = uniform_ptr((const char*)(xpl + (size_t)l_m0 * a.K + k0));
-      asm volatile("" : "+v"(xoffs[pc]));      // keep the offset a 32-bit VGPR: SGPR-base + voffset addressing
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + xoffs[pc]),
+      const char* gb = uniform_ptr((const char*)(xpl + (size_t)(l_m0 + pc * 8 * RPI) * a.K + k0));
+      asm volatile("" : "+v"(poff));      // keep the offset a 32-bit VGPR: SGPR-base + voffset addressing
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + poff),
                                        (__attribute__((address_space(3))) void*)(base + instr * 1024), 16, 0, 0);
     } else {
       const int instr = (pc - XI) * 8 + wave;
-      const char* gb = uniform_ptr((const char*)(wpl + (size_t)l_n0 * a.K + k0));
-      asm volatile("" : "+v"(woffs[pc - XI]));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + woffs[pc - XI]),
+      const char* gb = uniform_ptr((const char*)(wpl + (size_t)(l_n0 + (pc - XI) * 8 * RPI) * a.K + k0));
+      asm volatile("" : "+v"(poff));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + poff),
                                        (__attribute__((address_space(3))) void*)(base + XBYTES + instr * 1024), 16, 0,
                                        0);
     }
     if (KIND == 0 && pc == 0) {      // the tile's bias slice rides along with every fp16 step (256 B per wave)
-      const float* src = a.bias + l_n0 + wn * TN + lane;
+      // (lane offset from a volatile v_mbcnt: a hoisted 64-bit per-lane pointer would cost two VGPRs across the k-loop)
+      unsigned l4;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 2, %0" : "=v"(l4));
+      const char* src = uniform_ptr((const char*)(a.bias + l_n0 + wn * TN)) + l4;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(smem + BIAS_OFF +
                                                                                  ((l_ord & 1) * 8 + wave) * 256),
@@ -169,10 +180,33 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
         l_k = 0; ++l_ord; l_tile += stride;
         const int tm = l_tile / tiles_n;
         l_m0 = tm * BM; l_n0 = (l_tile - tm * tiles_n) * BN;
-        set_xoffs();
       }
     }
   };
+
+#if ZK_C8_PF
+  // touch this workgroup's share of the X lines of the step ZK_C8_PF steps past the load cursor (cursor kind CK static)
+  auto pf_issue = [&](auto ck_c) __attribute__((always_inline)) {
+    constexpr int CK = decltype(ck_c)::value;
+    constexpr int TK = (CK + ZK_C8_PF) & 1, DK = (CK + ZK_C8_PF) >> 1;
+    // (the first steps of the NEXT tile are not prefetched: their row block would have to be tracked in two more
+    // scalars per wave for 2 of a tile's 2·nk steps; past the tile the touch re-reads lines of this tile's last step)
+    const int k = min(l_k + DK, nk - 1), m0 = l_m0, tn = l_n0 / BN;
+    // everything per-lane is derived from a volatile v_mbcnt INSIDE the step: the kernel sits at the 256-VGPR cap and
+    // any lane-dependent value hipcc could hoist out of the loop would push a k-loop value into scratch
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    int rmax = min(tn * pf_rows + pf_rows, BM) - 1;
+    rmax = min(rmax, a.M - 1 - m0);
+    const int r0 = tn * pf_rows + (wave - (8 - pf_waves)) * 64;
+    const int r = min(r0 + ln, rmax);
+    const half_t* xpl = TK ? a.x_lo : a.x_hi;
+    const char* gb = uniform_ptr((const char*)(xpl + (size_t)m0 * a.K + k * BK));
+    const char* src = gb + (unsigned)r * (unsigned)(a.K * 2);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smem + PF_OFF + wave * 256), 4, 0, 0);
+  };
+#endif
 
   f4_t acc[RN][RM];
 #pragma unroll
@@ -397,6 +431,9 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
     using KN = std::integral_constant<int, KIND ^ 1>;
     // X tile 0 of this step, then per W tile i: the deferred MFMA of the previous step (old wf[i], X tile RM-1 in
     // xf[1]) followed by the read of this step's W fragment INTO wf[i] — one W register set serves both steps
+#if ZK_C8_PF
+    if (pf_wave) pf_issue(KN{});      // first vector-memory instruction of the step: a whole step to land before vmcnt(0)
+#endif
     ld_frag(xf[0], kind_c, xad, std::integral_constant<int, 0>{});
     static_for<RN>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
@@ -464,7 +501,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 
 template <int EPI>
 void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
-  constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144 + 8 * 512;
+  constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144 + 8 * 512 + 8 * 256;
   auto k = gemm_c8_kernel<EPI>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }

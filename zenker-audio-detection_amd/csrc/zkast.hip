@@ -752,6 +752,22 @@ int zk_features_get(zk_ctx* c, float* out, int32_t* n_windows, int32_t* n_frames
   return ZK_OK;
 }
 
+int zk_features_set(zk_ctx* c, const float* feats, int32_t n_windows, int32_t n_frames) {
+  if (!c) return ZK_E_ARG;
+  if (n_windows < 0 || n_frames < 1 || n_frames > ZK_MAXLEN) return fail(c, ZK_E_SHAPE, "feature slot of %d windows x %d frames (1..%d frames)", n_windows, n_frames, ZK_MAXLEN);
+  if (n_windows > 0 && !feats) return fail(c, ZK_E_ARG, "feats is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)n_windows * n_frames * ZK_NMEL * 4;
+  HIPCHK(c, c->feat.ensure(bytes ? bytes : 4));
+  if (bytes)
+    HIPCHK(c, hipMemcpyAsync(c->feat.p, feats, bytes, is_device_ptr(feats) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  c->feat_windows = n_windows;
+  c->feat_frames = n_frames;
+  // (a pageable host source is staged by the runtime before hipMemcpyAsync returns; pinned memory needs the sync)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ZK_OK;
+}
+
 int zk_ast_forward(zk_ctx* c, int stage, const float* input_values, const int32_t* win_idx, int32_t B, float* logits) {
   int rc = check_stage(c, stage);
   if (rc) return rc;

@@ -27,7 +27,7 @@ COMPUTE_MODES = {"f16": ZK_F16, "f16c8": ZK_F16C8, "f16x3": ZK_F16X3, 1: ZK_F16,
 SYMBOLS = [
     "zk_create", "zk_destroy", "zk_last_error", "zk_set_stream", "zk_set_async", "zk_synchronize",
     "zk_set_micro_batch", "zk_set_prune_last_layer", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_fx",
-    "zk_logmel", "zk_features_expand", "zk_features_get", "zk_ast_forward", "zk_softmax", "zk_two_stage", "zk_gate",
+    "zk_logmel", "zk_features_expand", "zk_features_get", "zk_features_set", "zk_ast_forward", "zk_softmax", "zk_two_stage", "zk_gate",
     "zk_comm_unique_id", "zk_comm_init", "zk_comm_destroy", "zk_comm_info", "zk_allgather_logits", "zk_comm_allgather_bytes",
     "zk_resample", "zk_wav_decode", "zk_audio_load", "zk_audio_get", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_prof_get_flops", "zk_debug_set_tap", "zk_debug_get_tap",
     "zk_test_layernorm", "zk_test_gemm", "zk_test_attention", "zk_test_split_c8",
@@ -89,6 +89,7 @@ def load_library() -> C.CDLL:
             "zk_logmel": (C.c_int, [vp, vp, i64, i64, i64, i32, i32]),
             "zk_features_expand": (C.c_int, [vp, f32, f32, i32, vp]),
             "zk_features_get": (C.c_int, [vp, vp, C.POINTER(i32), C.POINTER(i32)]),
+            "zk_features_set": (C.c_int, [vp, vp, i32, i32]),
             "zk_ast_forward": (C.c_int, [vp, C.c_int, vp, vp, i32, vp]),
             "zk_softmax": (C.c_int, [vp, vp, i32, i32, vp]),
             "zk_two_stage": (C.c_int, [vp, vp, i64, i64, i64, i32, i32, f32, f32, vp, vp, vp, vp]),
@@ -265,6 +266,16 @@ class Context:
         if nw:
             self._chk(self.lib.zk_features_get(self.h, out.ctypes.data, None, None), "zk_features_get")
         return out
+
+    def features_set(self, feats):
+        """compact un-normalised log-mel (N, n_frames, 128) float32, numpy or device tensor -> the feature slot"""
+        n, nf, nm = (int(v) for v in feats.shape)
+        if nm != 128:
+            raise ValueError(f"features must have 128 mel bins, got {nm}")
+        if not _is_torch(feats):
+            feats = np.ascontiguousarray(feats, dtype=np.float32)
+        p, _k = _ptr(feats)
+        self._chk(self.lib.zk_features_set(self.h, p, n, nf), "zk_features_set")
 
     # ---- transformer ----
     def ast_forward(self, stage: int, input_values, win_idx, B: int, logits_out):

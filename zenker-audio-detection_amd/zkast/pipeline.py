@@ -6,7 +6,7 @@ feature extraction, both AST forwards, the softmax and the gate running as HIP k
 from __future__ import annotations
 
 import argparse
-import glob
+import fnmatch
 import json
 import os
 import struct
@@ -105,51 +105,47 @@ def window_geometry(n_samples: int, window_sec: float, hop_sec: float, sr: int =
 
 
 def window_audio(audio: np.ndarray, window_sec: float, hop_sec: float, sr: int = SAMPLING_RATE) -> List[np.ndarray]:
-    win = int(window_sec * sr)
-    hop = int(hop_sec * sr)
-    out = []
-    for start in range(0, max(1, len(audio) - win + 1), hop):
-        segment = audio[start:start + win]
-        if len(segment) < win:
-            pad = np.zeros(win, dtype=audio.dtype)
-            pad[: len(segment)] = segment
-            segment = pad
-        out.append(segment)
-    return out
-
-
-def batch_iter(items, batch_size: int):
-    for i in range(0, len(items), batch_size):
-        yield items[i:i + batch_size]
+    """The window list of the reference's window_audio (:62-75) for callers that want it materialised (the product path
+    never does: the kernels cut windows out of the recording by index).  Full windows are zero-copy strided views of
+    `audio`; a recording shorter than one window gives its single zero-padded window."""
+    n, win, _hop = window_geometry(len(audio), window_sec, hop_sec, sr)
+    if len(audio) < win:
+        only = np.zeros(win, dtype=audio.dtype)
+        only[: len(audio)] = audio
+        return [only]
+    grid = np.lib.stride_tricks.sliding_window_view(audio, win)[::_hop]
+    return [grid[i] for i in range(n)]
 
 
 # ----------------- Model loading -----------------
 def load_stage_model(model_root: str, label_order: List[str], stage: int = 0, compute_mode="f16c8", device: int = 0):
-    """:86-98.  `stage` picks the library weight slot (0 for the Idle/Swallow model, 1 for Healthy/Zenker)."""
-    fx = ZkASTFeatureExtractor.from_pretrained(model_root, device=device)
+    """(fx, model) of one stage from a local checkpoint directory, labels set from `label_order` (:86-98).  `stage`
+    picks the library's weight slot (0: Idle/Swallow, 1: Healthy/Zenker); both stages stay resident side by side."""
     config = ZkASTConfig.from_pretrained(model_root)
-    label2id = {lbl: i for i, lbl in enumerate(label_order)}
-    config.label2id = label2id
-    config.id2label = {v: k for k, v in label2id.items()}
+    config.id2label = dict(enumerate(label_order))
+    config.label2id = {name: i for i, name in config.id2label.items()}
+    fx = ZkASTFeatureExtractor.from_pretrained(model_root, device=device)
     model = ZkASTForAudioClassification.from_pretrained(model_root, config=config, stage=stage,
                                                         compute_mode=compute_mode, device=device)
-    model.eval()
-    model.bind_feature_extractor(fx)
-    return fx, model
+    return fx, model.eval().bind_feature_extractor(fx)
 
 
 # ----------------- Inference -----------------
 def forward_probs(model, fx, windows: List[np.ndarray], batch_size: int) -> np.ndarray:
-    """:104-113, same contract: list of 1-D float32 windows -> (N, 2) float32 softmax probabilities; an empty list
-    gives np.zeros((0,)).  Written against the drop-in objects exactly like the original loop."""
-    probs_all = []
+    """Contract of the reference's forward_probs (:104-113): a list of 1-D float32 windows -> (N, labels) float32
+    softmax probabilities, np.zeros((0,)) for an empty list — through the drop-in extractor and model objects, one
+    `batch_size` slice at a time, so a script written against the HuggingFace classes runs unchanged."""
+    total = len(windows)
+    if total == 0:
+        return np.zeros((0,))
     ctx = _lib.get_context(getattr(model, "_device", 0))
-    for batch in batch_iter(windows, batch_size):
-        inputs = fx(batch, sampling_rate=SAMPLING_RATE, return_tensors="np")
-        feats = inputs[fx.model_input_names[0]]
-        logits = model(feats).logits
-        probs_all.append(ctx.softmax(np.asarray(logits)))
-    return np.concatenate(probs_all, axis=0) if probs_all else np.zeros((0,))
+    key = fx.model_input_names[0]
+    probs = np.empty((total, model.num_labels), dtype=np.float32)
+    for lo in range(0, total, batch_size):
+        hi = min(total, lo + batch_size)
+        feats = fx(windows[lo:hi], sampling_rate=SAMPLING_RATE, return_tensors="np")[key]
+        probs[lo:hi] = ctx.softmax(np.asarray(model(feats).logits))
+    return probs
 
 
 def forward_probs_recording(model, fx, audio: np.ndarray, window_sec: float, hop_sec: float,
@@ -166,63 +162,64 @@ def forward_probs_recording(model, fx, audio: np.ndarray, window_sec: float, hop
 
 # ----------------- File discovery -----------------
 def _wav_num_frames(path: str) -> int:
+    """Frames of a WAV file from its header alone (0 when unreadable)."""
     try:
-        wav, _ = read_wav(path)
-        return wav.shape[1]
-    except Exception:
+        _tag, ch, _sr, bits, raw = parse_wav(path)
+        return len(raw) // (ch * (bits // 8))
+    except (OSError, ValueError, struct.error):
         return 0
 
 
 def discover_two_files(root: str, patient_id: str, pattern: str) -> List[str]:
-    """:119-142."""
-    base = os.path.abspath(root)
-    matches = []
-    for dirpath, _, filenames in os.walk(base):
-        if patient_id not in dirpath:
-            continue
-        for fn in filenames:
-            if glob.fnmatch.fnmatch(fn, pattern):
-                matches.append(os.path.join(dirpath, fn))
-    matches = sorted(matches)
-    if len(matches) > 2:
-        lengths = [(p, _wav_num_frames(p)) for p in matches]
-        matches = [p for p, _ in sorted(lengths, key=lambda x: x[1], reverse=True)[:2]]
-    if len(matches) != 2:
-        raise ValueError(f"Expected exactly 2 files for patient {patient_id}, found {len(matches)}: {matches}")
-    return matches
+    """The two recordings of a patient (:119-142): files matching `pattern` in any directory below `root` whose path
+    contains the patient id; of more than two, the two LONGEST (ties: first in path order), longest first.
+    Anything but exactly two is a ValueError."""
+    found = sorted(os.path.join(folder, name)
+                   for folder, _dirs, names in os.walk(os.path.abspath(root)) if patient_id in folder
+                   for name in fnmatch.filter(names, pattern))
+    if len(found) > 2:
+        frames = {p: _wav_num_frames(p) for p in found}
+        found = sorted(found, key=frames.get, reverse=True)[:2]      # stable: equal lengths keep path order
+    if len(found) != 2:
+        raise ValueError(f"Expected exactly 2 files for patient {patient_id}, found {len(found)}: {found}")
+    return found
 
 
 # ----------------- Aggregation -----------------
 def summarize_stage_outputs(stage1_probs: np.ndarray, stage2_probs_or_none: List[Tuple[int, np.ndarray]],
                             stage1_label_order: List[str], stage2_label_order: List[str],
                             stage2_threshold: float = 0.5, use_argmax: bool = False) -> Dict[str, Any]:
-    """:148-195 (and ..._cache.py:243-297 for use_argmax), including the reference's quirk that the stage-1 counts
-    are recomputed by plain argmax, ignoring --stage1-threshold."""
-    stage1_preds = stage1_probs.argmax(axis=1)
-    stage2_aligned = [None] * len(stage1_preds)
-    for idx, probs in stage2_probs_or_none:
-        stage2_aligned[idx] = probs
-    idle_count = int((stage1_preds == 0).sum())
-    swallow_count = int((stage1_preds == 1).sum())
-    evaluated = [p for p in stage2_aligned if p is not None]
-    if use_argmax:
-        healthy_count = int(sum(1 for p in evaluated if np.argmax(p) == 0))
-        zenker_count = int(sum(1 for p in evaluated if np.argmax(p) == 1))
+    """Per-file summary dict, key for key what the reference writes (:148-195; `use_argmax`: ..._cache.py:243-297).
+
+    Two behaviours of the reference are kept on purpose because utils/aggregate_2stage_results.py consumes these
+    numbers: the stage-1 counts come from a PLAIN argmax of the probabilities — the --stage1-threshold gate is not
+    re-applied, so "stage1_swallow_windows" can exceed the windows stage 2 evaluated — and the stage-2 ratio divides by
+    that argmax count.  Stage-2 rows are taken in window order (a window listed twice counts once, last entry wins)."""
+    n = len(stage1_probs)
+    is_swallow = np.asarray(stage1_probs).argmax(axis=1) == 1 if n else np.zeros(0, bool)
+    swallow = int(is_swallow.sum())
+    by_window = {int(i): np.asarray(p) for i, p in stage2_probs_or_none}
+    evaluated = [by_window[i] for i in sorted(by_window)]
+    if evaluated:
+        rows = np.stack(evaluated)
+        zenker_mask = rows.argmax(axis=1) == 1 if use_argmax else rows[:, 1] >= stage2_threshold
+        healthy_mask = rows.argmax(axis=1) == 0 if use_argmax else rows[:, 1] < stage2_threshold
+        zenker, healthy = int(zenker_mask.sum()), int(healthy_mask.sum())
+        mean2 = np.mean(evaluated, axis=0).tolist()
     else:
-        healthy_count = int(sum(1 for p in evaluated if p[1] < stage2_threshold))
-        zenker_count = int(sum(1 for p in evaluated if p[1] >= stage2_threshold))
-    n = len(stage1_preds)
+        zenker = healthy = 0
+        mean2 = float("nan")            # what np.mean([]) gives the reference when nothing was evaluated
     return {
         "num_windows": int(n),
-        "stage1_idle_windows": idle_count,
-        "stage1_swallow_windows": swallow_count,
-        "stage1_swallow_ratio": (swallow_count / n) if n else 0.0,
-        "stage1_mean_probs": stage1_probs.mean(axis=0).tolist() if len(stage1_probs) else None,
-        "stage2_mean_probs_over_swallow": np.mean(evaluated, axis=0).tolist() if swallow_count else None,
-        "stage2_swallow_windows_evaluated": int(len(evaluated)),
-        "stage2_healthy_windows": healthy_count,
-        "stage2_zenker_windows": zenker_count,
-        "stage2_zenker_ratio_over_swallow": (zenker_count / swallow_count) if swallow_count else None,
+        "stage1_idle_windows": int(n - swallow),
+        "stage1_swallow_windows": swallow,
+        "stage1_swallow_ratio": swallow / n if n else 0.0,
+        "stage1_mean_probs": np.asarray(stage1_probs).mean(axis=0).tolist() if n else None,
+        "stage2_mean_probs_over_swallow": mean2 if swallow else None,
+        "stage2_swallow_windows_evaluated": len(evaluated),
+        "stage2_healthy_windows": healthy,
+        "stage2_zenker_windows": zenker,
+        "stage2_zenker_ratio_over_swallow": zenker / swallow if swallow else None,
     }
 
 
