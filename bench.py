@@ -55,9 +55,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed headline region (profiling runs): implies --no-fast --no-sweep --no-cpu, no configs[1] line")
-    ap.add_argument("--cpu-windows", type=int, default=4,
-                    help="CPU-baseline sample (default keeps the leg at ~20-30 s; SURVEY §8d's N=64 x 3: --cpu-windows 64 --cpu-repeats 3)")
-    ap.add_argument("--cpu-repeats", type=int, default=1)
+    ap.add_argument("--cpu-windows", type=int, default=64, help="CPU-baseline sample (SURVEY §8d: N = 64 windows)")
+    ap.add_argument("--cpu-repeats", type=int, default=3, help="CPU-baseline repeats, median reported (SURVEY §8d: 3)")
+    ap.add_argument("--cpu-budget-s", type=float, default=200.0,
+                    help="the CPU leg stops repeating rather than exceed this (the line states the repeats that ran)")
     args = ap.parse_args()
     if args.headline_only:
         args.no_fast = args.no_sweep = args.no_cpu = True
@@ -81,22 +82,35 @@ def main():
 
     ctx = lib.get_context(local_rank)
     ctx.set_micro_batch(args.micro_batch)
+    collective, rccl_error = "none (single GPU)", None
     if world > 1:      # host channel for the RCCL unique id; every collective of the bench then runs through the C ABI
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         tdist.init_process_group("gloo", rank=rank, world_size=world)
         try:
             zdist.init_comm(ctx, rank, world)
-            collective = "RCCL all-gather of both logit tables through the C ABI (zk_allgather_logits)"
-        except lib.ZkError as e:      # never expected on the 8-GPU node; keep the scaling run alive and say so
-            print(f"[bench] rank {rank}: RCCL communicator failed ({e}); falling back to a host gather over gloo", file=sys.stderr)
-            collective = "FALLBACK: host all-gather over gloo (RCCL communicator could not be created)"
-    use_rccl = world > 1 and ctx.comm_info()[1] == world
-    if world > 1:      # all ranks take the same path: one failed communicator sends everyone to the fallback
-        import torch as _t
-        ok = _t.tensor([1 if use_rccl else 0])
+        except lib.ZkError as e:      # never expected on the 8-GPU node
+            rccl_error = str(e)
+            print(f"[bench] rank {rank}: RCCL communicator failed ({e})", file=sys.stderr)
+    rccl_rank, rccl_world = ctx.comm_info()
+    use_rccl = world > 1 and rccl_world == world
+    if world > 1:
+        # All ranks take the same path: the decision is the MIN over ranks, made AFTER every rank has returned from the
+        # communicator init (an init that fails on one rank only leaves its peers inside ncclCommInitRank: that case
+        # ends with torch.distributed's timeout and a non-zero exit, it cannot fall back).
+        ok = torch.tensor([1 if use_rccl else 0])
         tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)
-        use_rccl = bool(ok.item())
+        agreed = bool(ok.item())
+        if not agreed and use_rccl:
+            ctx.comm_destroy()          # this rank had a communicator, a peer did not
+        use_rccl = agreed
+        if use_rccl:
+            collective = "RCCL all-gather of both logit tables through the C ABI (zk_allgather_logits)"
+        elif os.environ.get("ZK_BENCH_REQUIRE_RCCL") == "1":
+            raise SystemExit(f"[bench] rank {rank}: ZK_BENCH_REQUIRE_RCCL=1 and no RCCL communicator over {world} ranks "
+                             f"({rccl_error or 'a peer failed'})")
+        else:
+            collective = "FALLBACK: host all-gather over gloo (RCCL communicator could not be created)"
 
     S1 = (-1.1509622, 3.5340312)
     S2 = (-6.5, 2.75)
@@ -201,6 +215,14 @@ def main():
         ms, cnt, _ = prof[name]
         if cnt:
             roof_all[name] = dict(ms_per_launch=ms / cnt, launches=cnt, share=ms / (dt * 1e3))
+    # HBM-bound front end (reported separately, never folded into the headline fraction).  Algorithmic bytes
+    # per window: 64,000 B of audio in + 50,176 B of log-mel out; one launch covers B windows.
+    if "logmel" in roof_all:
+        lm = roof_all["logmel"]
+        lm_bytes = B * (64000 + 50176)
+        lm.update(algorithmic_bytes_per_launch=lm_bytes, gb_per_s=lm_bytes / (lm["ms_per_launch"] * 1e-3) / 1e9,
+                  frac_of_hbm_peak=lm_bytes / (lm["ms_per_launch"] * 1e-3) / 8.0e12,
+                  note="fp64 FFT in LDS: VALU / barrier-bound, not HBM-bound; 0.06 % of the step")
     executed = sum(prof[n][2] for n in ("gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention"))
     dom = max((k for k in roof_all if "tflops" in roof_all[k]), key=lambda k: roof_all[k]["share"])
     roofline = {"kernel": dom, "bound": "mfma", "achieved": roof_all[dom]["tflops"], "peak": PEAK_F16_DENSE / 1e12,
@@ -231,7 +253,9 @@ def main():
                                f"0.5 s, gate rate g={K / B:.2f}", "windows_per_gpu": B, "stage2_windows_per_gpu": K,
                    "micro_batch": args.micro_batch, "weights": "synthetic splitmix64 'wide' set (seeds 21/22), stage-1 "
                    f"swallow bias shifted by {shift:+.3f} so that thr1 alone sets the gate rate",
-                   "parallelism": f"window-sharded x{world}, {collective}" if world > 1 else "single GPU"},
+                   "parallelism": f"window-sharded x{world}, {collective}" if world > 1 else "single GPU",
+                   "rccl_world": rccl_world if use_rccl else (1 if world == 1 else 0),
+                   "collective_fallback": bool(world > 1 and not use_rccl)},
         "roofline": roofline,
         "roofline_end_to_end": {"algorithmic_gflop_per_window_stage": FLOP_PER_WINDOW_STAGE / 1e9,
                                 "achieved_tflops_per_gpu": e2e_flops / 1e12, "frac_of_f16_dense_peak": e2e_flops / PEAK_F16_DENSE,
@@ -290,46 +314,48 @@ def main():
         m1.set_compute_mode(args.mode)
         out["config1_stage1_b256"] = cfg1
 
-    # ---- CPU baseline: the oracle (numpy restatement) on this box's host cores, rank 0, N=1 only ----
+    # ---- resample line (HBM GB/s of the 48 -> 16 kHz polyphase kernel, reported separately) ----
+    if rank == 0 and world == 1 and not args.headline_only:
+        n48 = 48000 * 60 * 5                                   # 5 min at 48 kHz, device-resident fp32
+        a48 = torch.randn(n48, device=dev) * 0.1
+        o16 = torch.empty((n48 + 2) // 3, dtype=torch.float32, device=dev)
+        ctx.resample_into(a48, n48, 48000, 16000, o16)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.resample_into(a48, n48, 48000, 16000, o16)
+        barrier()
+        rs = (time.perf_counter() - t0) / 5
+        rs_bytes = 4 * (n48 + o16.numel())
+        out["resample_48k_to_16k"] = {"ms_per_launch": rs * 1e3, "algorithmic_bytes_per_launch": rs_bytes,
+                                      "gb_per_s": rs_bytes / rs / 1e9, "frac_of_hbm_peak": rs_bytes / rs / 8.0e12,
+                                      "sample": "5 min of 48 kHz fp32 audio resident in HBM, host-timed incl. launch"}
+        del a48, o16
+
+    # ---- CPU baseline: the build's own fp32 restatement on torch-CPU operators + the numpy log-mel
+    #      (oracle/ast_torch_cpu.py, pinned against the golden transformers logits in tests/test_oracle.py) on this box's
+    #      host cores: N = 64 windows, both stages for every window (the headline's g = 1.0), 3 repeats, median ----
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import ast_oracle as orc
+        from oracle import ast_torch_cpu as tcpu
         n_cpu = args.cpu_windows
         wins = orc.window_audio(rec[: win + (n_cpu - 1) * hop])
-        W1, W2 = orc.ASTWeights(sd1s), orc.ASTWeights(sd2)
-        try:                                    # report the BLAS threads actually used, not the box's core count
-            from threadpoolctl import threadpool_info
-            blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
-        except Exception:
-            blas_threads = None
         allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-        reps = []
-        for _ in range(max(1, args.cpu_repeats)):
-            t0 = time.perf_counter()
-            f1 = orc.extract_features(wins, *S1)
-            t1 = time.perf_counter()
-            l1 = orc.ast_forward(f1, W1)
-            t2 = time.perf_counter()
-            f2 = orc.extract_features(wins, *S2)
-            t3 = time.perf_counter()
-            orc.ast_forward(f2, W2)
-            t4 = time.perf_counter()
-            reps.append((t4 - t0, (t1 - t0) + (t3 - t2), (t2 - t1) + (t4 - t3)))
-            del f2
-        reps.sort()
-        tc, t_mel, t_fwd = reps[len(reps) // 2]
-        out["cpu_baseline"] = {"value": n_cpu / tc, "unit": "windows/s",
-                               "cores": blas_threads if blas_threads else allowed, "kind": "port",
-                               "mel_windows_per_s_per_stage": 2 * n_cpu / t_mel,
-                               "forward_windows_per_s_per_stage": 2 * n_cpu / t_fwd,
-                               "sample": f"{n_cpu} windows x (log-mel + AST) x 2 stages, numpy/BLAS fp32 oracle, median of "
-                                         f"{len(reps)} run(s), {tc:.1f} s wall each (mel {t_mel:.1f} s single-threaded "
-                                         f"numpy, forward {t_fwd:.1f} s on {blas_threads} BLAS threads); cpus allowed "
-                                         f"{allowed}, os.cpu_count {os.cpu_count()}"}
+        r = tcpu.time_two_stage(wins, sd1s, sd2, S1, S2, repeats=args.cpu_repeats, budget_s=args.cpu_budget_s)
+        out["cpu_baseline"] = {"value": n_cpu / r["seconds"], "unit": "windows/s", "cores": r["threads"], "kind": "port",
+                               "mel_windows_per_s_per_stage": 2 * n_cpu / r["mel_seconds"],
+                               "forward_windows_per_s_per_stage": 2 * n_cpu / r["forward_seconds"],
+                               "sample": f"{n_cpu} windows x (log-mel + AST forward) x 2 stages, fp32 restatement on torch-CPU "
+                                         f"operators + numpy fp64 log-mel, median of {r['repeats']} repeat(s) (asked "
+                                         f"{args.cpu_repeats}), {r['seconds']:.1f} s each (mel {r['mel_seconds']:.1f} s, forward "
+                                         f"{r['forward_seconds']:.1f} s); {r['threads']} threads = cores this process may use "
+                                         f"(affinity {allowed}, cgroup quota applied), os.cpu_count {os.cpu_count()}"}
         # re-run the headline mode once so the comparison is against its logits
         step()
         barrier()
-        out["parity_in_bench"] = {"stage1_logit_max_abs_err_vs_oracle": float(
-            np.abs(s1_logits.cpu().numpy()[:n_cpu] - l1).max()), "windows": n_cpu}
+        out["parity_in_bench"] = {"stage1_logit_max_abs_err_vs_cpu_restatement": float(
+            np.abs(s1_logits.cpu().numpy()[:n_cpu] - r["logits1"]).max()), "windows": n_cpu,
+            "note": "checker = oracle/ast_torch_cpu.py (fp32, numpy-branch log-mel: the extractor branch this build pins; a "
+                    "torchaudio-equipped reference install takes the kaldi fp32 branch, see DESIGN.md (c))"}
 
     if rank == 0:
         print(json.dumps(out))

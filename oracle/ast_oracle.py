@@ -130,11 +130,50 @@ def fbank_frames(waveform: np.ndarray) -> np.ndarray:
     return np.log(melspec).astype(np.float32)             # (:1002,:1015)
 
 
-def extract_features(windows, mean: float, std: float, do_normalize: bool = True) -> np.ndarray:
-    """list/array of (16000,) fp32 -> (B,1024,128) fp32, i.e. ASTFeatureExtractor.__call__(...)['input_values']."""
+def fbank_frames_kaldi_fp32(waveform: np.ndarray) -> np.ndarray:
+    """PARITY UNPINNED.  (T,) fp32 -> (num_frames,128) fp32: the OTHER branch of ``_extract_fbank_features``
+    ($TF/…/feature_extraction_audio_spectrogram_transformer.py:116-123), taken when torchaudio is installed — which a
+    reference install has (requirements.txt:12; src/test_long_audio_windows_2stage.py:39 imports it unconditionally):
+    ``torchaudio.compliance.kaldi.fbank(waveform, sample_frequency=16000, window_type="hanning", num_mel_bins=128)``.
+
+    torchaudio is NOT in this image, so this is a restatement of its published algorithm from the library's
+    documentation and general knowledge of ``torchaudio/compliance/kaldi.py`` (defaults: 25 ms / 10 ms frames, snip_edges,
+    dither 0, remove_dc_offset, pre-emphasis 0.97 over a replicate-padded frame, symmetric Hann, zero-pad to 512,
+    ``torch.fft.rfft`` -> |.|^2, mel banks built in FLOAT32 from ``1127 ln(1 + f/700)`` with the Nyquist bin's weight
+    forced to zero, ``max(eps_fp32).log()``), written with the same torch float32 operators torchaudio uses.  No fixture
+    can pin it here; it exists to MEASURE how far the two branches move the features and the logits
+    (tests/test_oracle.py::test_extractor_branch_gap).  Same arithmetic as the numpy branch, but float32 throughout
+    instead of float64 framing + complex64 spectrum."""
+    import torch
+    x = torch.from_numpy(np.ascontiguousarray(waveform, dtype=np.float32))
+    n_frames = 1 + (x.numel() - FRAME_LEN) // HOP_LEN
+    fr = x.as_strided((n_frames, FRAME_LEN), (HOP_LEN, 1))                       # _get_strided, snip_edges=True
+    fr = fr - fr.mean(dim=1, keepdim=True)                                       # remove_dc_offset
+    prev = torch.nn.functional.pad(fr.unsqueeze(0), (1, 0), mode="replicate").squeeze(0)[:, :-1]
+    fr = fr - PREEMPH * prev                                                     # x[0] - 0.97 x[0] at the left edge
+    fr = fr * torch.hann_window(FRAME_LEN, periodic=False, dtype=torch.float32)  # window_type="hanning"
+    fr = torch.nn.functional.pad(fr, (0, FFT_LEN - FRAME_LEN))                   # round_to_power_of_two
+    power = torch.fft.rfft(fr).abs().pow(2.0)                                    # use_power=True, (F,257) fp32
+    # get_mel_banks(128, 512, 16000, low 20, high 0 -> nyquist), all float32
+    mel = lambda f: 1127.0 * torch.log(1.0 + f / 700.0)                          # noqa: E731
+    lo, hi = mel(torch.tensor(20.0)), mel(torch.tensor(float(SR // 2)))
+    delta = (hi - lo) / (N_MEL + 1)
+    b = torch.arange(N_MEL, dtype=torch.float32).unsqueeze(1)
+    left, center, right = lo + b * delta, lo + (b + 1.0) * delta, lo + (b + 2.0) * delta
+    fft_mel = mel((SR / FFT_LEN) * torch.arange(FFT_LEN // 2, dtype=torch.float32)).unsqueeze(0)      # 256 bins
+    banks = torch.clamp(torch.minimum((fft_mel - left) / (center - left), (right - fft_mel) / (right - center)), min=0.0)
+    banks = torch.nn.functional.pad(banks, (0, 1))                               # Nyquist column = 0 -> (128,257)
+    e = torch.mm(power, banks.T)
+    return torch.clamp(e, min=float(np.finfo(np.float32).eps)).log().numpy()     # use_log_fbank
+
+
+def extract_features(windows, mean: float, std: float, do_normalize: bool = True, branch: str = "numpy") -> np.ndarray:
+    """list/array of (16000,) fp32 -> (B,1024,128) fp32, i.e. ASTFeatureExtractor.__call__(...)['input_values'].
+    branch "numpy" (pinned, the branch this image and the build use) or "kaldi" (parity unpinned, see above)."""
+    frames = fbank_frames if branch == "numpy" else fbank_frames_kaldi_fp32
     out = np.zeros((len(windows), MAX_LEN, N_MEL), dtype=np.float32)
     for i, w in enumerate(windows):
-        fb = fbank_frames(np.squeeze(np.asarray(w, dtype=np.float32)))
+        fb = frames(np.squeeze(np.asarray(w, dtype=np.float32)))
         n = min(fb.shape[0], MAX_LEN)
         out[i, :n] = fb[:n]                               # ZeroPad2d / truncate (:143-151)
     if do_normalize:

@@ -87,9 +87,34 @@ def make_heavy(nrm):
     np.savez_compressed(os.path.join(HERE, "model_heavy.npz"), **f)
 
 
+def make_sens(nrm):
+    """F3c: the INPUT-SENSITIVE weight set ("sens", seed 31: patch filters dominate the embedding, content-peaked
+    attention, 2x head gain) through the real transformers fp32 model on all six golden windows: logits that span > 6
+    between windows and whose argmax flips, plus the usual residual-stream checkpoints."""
+    f = {"input_windows": np.arange(6), "tokens": np.array(TOKENS)}
+    m = hf_model(31, "sens")
+    out = m(torch.from_numpy(nrm[:6]), output_hidden_states=True)
+    hs = out.hidden_states
+    seq = m.audio_spectrogram_transformer.layernorm(hs[-1])
+    lg = out.logits.numpy()
+    f["sens_logits"] = lg
+    for nm, t in [("emb", hs[0]), ("layer0", hs[1]), ("layer5", hs[6]), ("layer11", hs[12]), ("final_ln", seq)]:
+        f[f"sens_{nm}_tok"] = t[:, TOKENS].numpy()
+        f[f"sens_{nm}_norm"] = t.norm(dim=-1).numpy()
+    margin = lg[:, 1] - lg[:, 0]
+    print("sens logits", lg.tolist(), "margins", margin.tolist())
+    assert np.ptp(lg, axis=0).max() > 3.0 and margin.min() < -1.0 and margin.max() > 1.0, "set is not input-sensitive"
+    np.savez_compressed(os.path.join(HERE, "model_sens.npz"), **f)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
+    if "--sens-only" in sys.argv:       # adds model_sens.npz without touching the other fixtures
+        fx = ASTFeatureExtractor(mean=S1_MEAN, std=S1_STD)
+        nrm = fx(list(synth.golden_windows()), sampling_rate=16000, return_tensors="np")["input_values"]
+        make_sens(nrm)
+        return
     if "--heavy-only" in sys.argv:      # adds model_heavy.npz without touching the other fixtures
         fx = ASTFeatureExtractor(mean=S1_MEAN, std=S1_STD)
         nrm = fx(list(synth.golden_windows()), sampling_rate=16000, return_tensors="np")["input_values"]
@@ -155,6 +180,7 @@ def main():
     f3["tokens"] = np.array(TOKENS)
     np.savez_compressed(os.path.join(HERE, "model.npz"), **f3)
     make_heavy(nrm)
+    make_sens(nrm)
 
     # ---------------- F4: cascade ----------------
     w16 = synth.synth_windows(seed=3, n_windows=16)

@@ -151,10 +151,13 @@ def test_two_rank_rccl_cascade_on_one_gpu():
     import queue
     try:
         res = [q.get(timeout=150) for _ in range(2)]
-    except queue.Empty:          # a communicator bootstrap that neither completes nor fails: stop exactly these two
-        for p in procs:
+    except queue.Empty:          # a communicator bootstrap that neither completes nor fails is a FAILURE to diagnose,
+        for p in procs:          # not a skip: stop exactly these two processes and report what is known about them
             p.terminate()
-        pytest.skip("RCCL communicator of two ranks on one device did not come up within 150 s")
+        for p in procs:
+            p.join(30)
+        pytest.fail("two-rank RCCL communicator neither came up nor reported a refusal within 150 s "
+                    f"(worker exit codes {[p.exitcode for p in procs]}); a hang in ncclCommInitRank / the first gather")
     for p in procs:
         p.join(120)
     if any(r[1] == "refused" for r in res):

@@ -137,6 +137,40 @@ def test_heavy_tailed_weight_set_all_modes(golden_dir):
     assert errs["f16c8"] <= TOL and errs["f16x3"] <= TOL and errs["f16"] <= 5e-2
 
 
+def test_input_sensitive_weight_set_parity_modes(golden_dir):
+    """The `sens` set (patch filters dominate the embedding, content-peaked attention, 2x head gain): the six golden
+    windows' logits span > 6 and their argmax flips, so nothing between the log-mel and the head is attenuated before it
+    reaches the comparison.  Against the real transformers fp32 run (tests/golden/model_sens.npz), end to end from the
+    AUDIO (device log-mel included): 1e-3 on the logits, 2e-4 on the residual-stream checkpoints, identical gate
+    decisions, in both parity modes."""
+    from zkast import ZkASTFeatureExtractor, lib, synth
+    g = np.load(os.path.join(golden_dir, "model_sens.npz"))
+    fb = np.load(os.path.join(golden_dir, "fbank.npz"))
+    ref = g["sens_logits"]
+    assert np.ptp(ref, axis=0).max() > 3.0
+    fx = ZkASTFeatureExtractor(mean=float(fb["mean"]), std=float(fb["std"]))
+    feats = fx(list(synth.golden_windows()), sampling_rate=16000, return_tensors="np")["input_values"]
+    model, _ = _model(31, "sens", 0, mean=float(fb["mean"]), std=float(fb["std"]))
+    ctx = lib.get_context(0)
+    toks = g["tokens"]
+    for mode in ("f16c8", "f16x3"):
+        model.set_compute_mode(mode)
+        for layer, name in [(-1, "emb"), (0, "layer0"), (5, "layer5"), (11, "layer11")]:
+            ctx.debug_tap(layer)
+            logits = model(feats).logits
+            h = ctx.debug_get_tap(6)
+            ref_tok, ref_norm = g[f"sens_{name}_tok"], g[f"sens_{name}_norm"]
+            assert np.abs(h[:, toks] - ref_tok).max() <= 2e-4 * np.abs(ref_tok).max(), (mode, name)
+            assert np.abs(np.linalg.norm(h, axis=-1) - ref_norm).max() <= 2e-4 * ref_norm.max(), (mode, name)
+        ctx.debug_tap(-2)
+        err = float(np.abs(logits - ref).max())
+        print(f"[sens] {mode} max-abs logit err vs transformers fp32: {err:.3e} (logit spread {np.ptp(ref, axis=0).max():.1f})")
+        assert err <= TOL, mode
+        assert np.array_equal(logits.argmax(1), ref.argmax(1))
+    model.set_compute_mode("f16")
+    print(f"[sens] f16   max-abs logit err vs transformers fp32: {np.abs(model(feats).logits - ref).max():.3e}")
+
+
 def test_v4_key_scheme_loads_identically(G):
     from zkast import ZkASTConfig, ZkASTForAudioClassification, synth
     sd = synth.make_ast_weights(12, "init")

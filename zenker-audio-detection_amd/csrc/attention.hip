@@ -92,19 +92,22 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   // ---- Q fragments (B operand: lane holds Q[q = lane&31][d = 16ks + 8*half + j]) ----
   const int q_row = qt * QT + wave * 32 + (lane & 31);
   const int q_ld = q_row < S_ ? q_row : S_ - 1;
-  h8_t qh[4], ql[(SPLIT && !C8) ? 4 : 1];
+  h8_t qh[4], ql[(SPLIT && !C8) ? 4 : 1];      // ql: q's fp16 lo fragments, kept only where the 3-term split reads them later
   i8v_t qc[C8 ? 2 : 1];      // C8: q' for the two 64-byte-deep fp8 MFMAs (ks = 2t, 2t+1)
   {
     const size_t off = (tok0 + q_ld) * QKV_LD + head * ZK_HEAD_DIM + 8 * half;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       qh[ks] = *(const h8_t*)(qkv_hi + off + ks * 16);
-      if constexpr (SPLIT) ql[ks] = *(const h8_t*)(qkv_lo + off + ks * 16);
+      // q's lo fragment of this k-step lives in a local: C8 needs it only here (ql[] then has ONE element, and indexing
+      // it with ks would run past its end), the 3-term split keeps the re-split value in ql[ks] below
+      h8_t qlo = {};
+      if constexpr (SPLIT) qlo = *(const h8_t*)(qkv_lo + off + ks * 16);
       // fold the softmax scale and the change to the log2 domain into q once: q <- q * (d^-1/2 * log2 e)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float qf = (float)qh[ks][e];
-        if constexpr (SPLIT) qf += (float)ql[ks][e];
+        if constexpr (SPLIT) qf += (float)qlo[e];
         qf *= 0.125f * 1.4426950408889634f;
         qh[ks][e] = (half_t)qf;
         if constexpr (SPLIT && !C8) ql[ks][e] = (half_t)(qf - (float)qh[ks][e]);

@@ -86,6 +86,8 @@ __device__ __forceinline__ h4_t zk_lo4(const float* v, h4_t hi, int fmt) {
 enum { ZK_EPI_STORE = 0, ZK_EPI_GELU = 1, ZK_EPI_RESID = 2, ZK_EPI_PATCH = 3 };
 
 struct zk_gemm_args {
+  // x planes: zk_launch_gemm_c8 stages the last row block WHOLE, so both planes must be readable up to row
+  // ceil(M/256)*256 (the workspace and the test hooks allocate one spare tile; what those rows hold never reaches a store)
   const half_t* x_hi;  // [M, K] activations (row-major, K contiguous)
   const half_t* x_lo;  // or nullptr
   const half_t* w_hi;  // [N, K] weights (nn.Linear layout)

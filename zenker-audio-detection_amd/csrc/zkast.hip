@@ -36,6 +36,27 @@ struct DevBuf {
   template <class T> T* as() const { return (T*)p; }
 };
 
+// Device allocations of one test-hook call: freed when the hook returns, on EVERY path (the HIPCHK / fail() early
+// returns included).  The stream is drained first so that no queued kernel still reads a buffer being freed.
+struct DevArena {
+  hipStream_t stream;
+  std::vector<void*> ptrs;
+  explicit DevArena(hipStream_t s) : stream(s) {}
+  DevArena(const DevArena&) = delete;
+  DevArena& operator=(const DevArena&) = delete;
+  template <class T> hipError_t alloc(T** out, size_t bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    *out = (T*)p;
+    if (e == hipSuccess) ptrs.push_back(p);
+    return e;
+  }
+  ~DevArena() {
+    if (!ptrs.empty()) (void)hipStreamSynchronize(stream);
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+};
+
 struct PlaneBuf {
   DevBuf hi, lo, rowexp;      // rowexp: allocated only for the LayerNorm outputs (zk_planes::rowexp)
   zk_planes get(bool split, int lo_fmt = ZK_LO_F16) const {
@@ -892,8 +913,8 @@ int zk_audio_load(zk_ctx* c, const void* data, int64_t n_bytes, int32_t format_t
   c->async = true;      // one sync at the end: upload -> decode -> resample stay queued on the stream
   int rc;
   if (sr == target_sr) {
-    HIPCHK(c, c->audio_slot.ensure((size_t)n_frames * 4));
-    rc = zk_wav_decode(c, data, n_bytes, format_tag, bits, channels, c->audio_slot.as<float>());
+    rc = hipSuccess == c->audio_slot.ensure((size_t)n_frames * 4) ? ZK_OK : fail(c, ZK_E_NOMEM, "audio buffer");
+    if (!rc) rc = zk_wav_decode(c, data, n_bytes, format_tag, bits, channels, c->audio_slot.as<float>());
     if (!rc) c->audio_slot_n = n_frames;
   } else {
     const int64_t n_out = resampled_len(n_frames, sr, target_sr);
@@ -1028,11 +1049,12 @@ int zk_test_layernorm(zk_ctx* c, const float* x, const float* gamma, const float
                       int32_t nsplit, float* out) {
   if (!c) return ZK_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  DevArena mem(c->stream);
   const size_t n = (size_t)rows * ZK_HIDDEN;
   float *dx, *dg, *db; half_t *hi, *lo; int32_t* dexp;
-  HIPCHK(c, hipMalloc((void**)&dx, n * 4)); HIPCHK(c, hipMalloc((void**)&dg, ZK_HIDDEN * 4)); HIPCHK(c, hipMalloc((void**)&db, ZK_HIDDEN * 4));
-  HIPCHK(c, hipMalloc((void**)&hi, n * 2)); HIPCHK(c, hipMalloc((void**)&lo, n * 2));
-  HIPCHK(c, hipMalloc((void**)&dexp, (size_t)rows * 4)); HIPCHK(c, hipMemsetAsync(dexp, 0, (size_t)rows * 4, c->stream));
+  HIPCHK(c, mem.alloc(&dx, n * 4)); HIPCHK(c, mem.alloc(&dg, ZK_HIDDEN * 4)); HIPCHK(c, mem.alloc(&db, ZK_HIDDEN * 4));
+  HIPCHK(c, mem.alloc(&hi, n * 2)); HIPCHK(c, mem.alloc(&lo, n * 2));
+  HIPCHK(c, mem.alloc(&dexp, (size_t)rows * 4)); HIPCHK(c, hipMemsetAsync(dexp, 0, (size_t)rows * 4, c->stream));
   HIPCHK(c, hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dg, gamma, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(db, beta, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
@@ -1056,7 +1078,6 @@ int zk_test_layernorm(zk_ctx* c, const float* x, const float* gamma, const float
       for (int k = 0; k < ZK_HIDDEN; ++k) mx = fmaxf(mx, fabsf(half_bits_to_float(h[(size_t)r * ZK_HIDDEN + k])));
       if (mx > 0.f && !(mx > 111.9f && mx <= 224.1f)) ++bad;
     }
-  (void)hipFree(dx); (void)hipFree(dg); (void)hipFree(db); (void)hipFree(hi); (void)hipFree(lo); (void)hipFree(dexp);
   if (bad) return fail(c, ZK_E_STATE, "layernorm c8 plane: %zu value bytes are not the fp8 rounding of the (row-scaled) output / rows off (112, 224]", bad);
   return ZK_OK;
 }
@@ -1069,20 +1090,21 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   if (N % 256 || K % 64 || M < 1) return fail(c, ZK_E_SHAPE, "zk_test_gemm: need N%%256==0, K%%64==0");
   if (epi == ZK_EPI_PATCH && (M % ZK_NPATCH || N != ZK_HIDDEN)) return fail(c, ZK_E_SHAPE, "PATCH epilogue: M%%1212==0, N==768");
   HIPCHK(c, hipSetDevice(c->device));
+  DevArena mem(c->stream);
   const size_t nx = (size_t)M * K, nw = (size_t)N * K;
   const size_t orows = epi == ZK_EPI_PATCH ? (size_t)(M / ZK_NPATCH) * ZK_SEQ : (size_t)M;
   const size_t no = orows * N;
   float *dx, *dw, *dbias, *dres = nullptr, *dpos = nullptr; half_t *xh, *xl, *wh, *wl, *oh = nullptr, *ol = nullptr;
   int32_t* dexp = nullptr;
-  HIPCHK(c, hipMalloc((void**)&dx, nx * 4)); HIPCHK(c, hipMalloc((void**)&dw, nw * 4)); HIPCHK(c, hipMalloc((void**)&dbias, (size_t)N * 4));
-  // x planes are padded by one 256-row tile (the kernels clamp their M-tail rows to M-1; the pad only keeps a mistake
-  // in that clamp from faulting)
+  HIPCHK(c, mem.alloc(&dx, nx * 4)); HIPCHK(c, mem.alloc(&dw, nw * 4)); HIPCHK(c, mem.alloc(&dbias, (size_t)N * 4));
+  // x planes are padded by one 256-row tile: the ZK_F16C8 kernel reads the last row block whole (zk_gemm_args: rows
+  // M .. ceil(M/256)*256 must be readable; their products are never stored)
   const size_t nxp = nx + (size_t)256 * K;
-  HIPCHK(c, hipMalloc((void**)&xh, nxp * 2)); HIPCHK(c, hipMalloc((void**)&xl, nxp * 2));
+  HIPCHK(c, mem.alloc(&xh, nxp * 2)); HIPCHK(c, mem.alloc(&xl, nxp * 2));
   // (memsets go on the context's stream: a plain hipMemset runs on the NULL stream, which the non-blocking context stream
   // does not wait for — it could land after the kernels below had written the buffer)
   HIPCHK(c, hipMemsetAsync(xh, 0, nxp * 2, c->stream)); HIPCHK(c, hipMemsetAsync(xl, 0, nxp * 2, c->stream));
-  HIPCHK(c, hipMalloc((void**)&wh, nw * 2)); HIPCHK(c, hipMalloc((void**)&wl, nw * 2));
+  HIPCHK(c, mem.alloc(&wh, nw * 2)); HIPCHK(c, mem.alloc(&wl, nw * 2));
   HIPCHK(c, hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dw, w, nw * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice));
   zk_launch_split_f32(dx, (int64_t)nx, 1.f, xh, xl, c->stream);
@@ -1090,16 +1112,16 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   int w_exp = 0;
   if (nsplit == ZK_F16C8) {      // lo planes become c8 byte pairs
     w_exp = c8_exponent(w, nw);
-    HIPCHK(c, hipMalloc((void**)&dexp, (size_t)(M + 256) * 4)); HIPCHK(c, hipMemsetAsync(dexp, 0, (size_t)(M + 256) * 4, c->stream));
+    HIPCHK(c, mem.alloc(&dexp, (size_t)(M + 256) * 4)); HIPCHK(c, hipMemsetAsync(dexp, 0, (size_t)(M + 256) * 4, c->stream));
     zk_launch_split_rows_c8(dx, M, K, xh, xl, dexp, c->stream);      // row-scaled planes, as LayerNorm writes them
     zk_launch_split_c8(dw, (int64_t)nw, w_exp, 1, wl, c->stream);
   }
   if (epi == ZK_EPI_RESID || epi == ZK_EPI_PATCH) {
-    HIPCHK(c, hipMalloc((void**)&dres, no * 4));
+    HIPCHK(c, mem.alloc(&dres, no * 4));
     HIPCHK(c, hipMemcpy(dres, out, no * 4, hipMemcpyHostToDevice));
-    if (epi == ZK_EPI_PATCH) { HIPCHK(c, hipMalloc((void**)&dpos, (size_t)ZK_SEQ * N * 4)); HIPCHK(c, hipMemcpy(dpos, pos, (size_t)ZK_SEQ * N * 4, hipMemcpyHostToDevice)); }
+    if (epi == ZK_EPI_PATCH) { HIPCHK(c, mem.alloc(&dpos, (size_t)ZK_SEQ * N * 4)); HIPCHK(c, hipMemcpy(dpos, pos, (size_t)ZK_SEQ * N * 4, hipMemcpyHostToDevice)); }
   } else {
-    HIPCHK(c, hipMalloc((void**)&oh, no * 2)); HIPCHK(c, hipMalloc((void**)&ol, no * 2));
+    HIPCHK(c, mem.alloc(&oh, no * 2)); HIPCHK(c, mem.alloc(&ol, no * 2));
     HIPCHK(c, hipMemsetAsync(ol, 0, no * 2, c->stream));
   }
   zk_gemm_args a;
@@ -1124,8 +1146,6 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
     }
     if (bad) return fail(c, ZK_E_STATE, "gemm GELU c8 plane: %zu value bytes are not the fp8 rounding of the output", bad);
   }
-  for (void* p : {(void*)dx, (void*)dw, (void*)dbias, (void*)dres, (void*)dpos, (void*)xh, (void*)xl, (void*)wh, (void*)wl, (void*)oh, (void*)ol, (void*)dexp})
-    if (p) (void)hipFree(p);
   return ZK_OK;
 }
 
@@ -1133,10 +1153,11 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
 int zk_test_attention(zk_ctx* c, const float* qkv, int32_t W, int32_t nsplit, float* out) {
   if (!c) return ZK_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  DevArena mem(c->stream);
   const size_t rows = (size_t)W * ZK_SEQ, nq = rows * 3 * ZK_HIDDEN, no = rows * ZK_HIDDEN;
   float* dq; half_t *qh, *ql, *oh, *ol;
-  HIPCHK(c, hipMalloc((void**)&dq, nq * 4)); HIPCHK(c, hipMalloc((void**)&qh, nq * 2)); HIPCHK(c, hipMalloc((void**)&ql, nq * 2));
-  HIPCHK(c, hipMalloc((void**)&oh, no * 2)); HIPCHK(c, hipMalloc((void**)&ol, no * 2));
+  HIPCHK(c, mem.alloc(&dq, nq * 4)); HIPCHK(c, mem.alloc(&qh, nq * 2)); HIPCHK(c, mem.alloc(&ql, nq * 2));
+  HIPCHK(c, mem.alloc(&oh, no * 2)); HIPCHK(c, mem.alloc(&ol, no * 2));
   HIPCHK(c, hipMemsetAsync(ol, 0, no * 2, c->stream));
   HIPCHK(c, hipMemcpy(dq, qkv, nq * 4, hipMemcpyHostToDevice));
   zk_launch_split_f32(dq, (int64_t)nq, 1.f, qh, ql, c->stream);
@@ -1156,21 +1177,20 @@ int zk_test_attention(zk_ctx* c, const float* qkv, int32_t W, int32_t nsplit, fl
     if (lf == ZK_LO_C8 && !c8_value_byte_ok(l[i], out[i])) ++bad;
   }
   if (bad) return fail(c, ZK_E_STATE, "attention c8 plane: %zu value bytes are not the fp8 rounding of the output", bad);
-  (void)hipFree(dq); (void)hipFree(qh); (void)hipFree(ql); (void)hipFree(oh); (void)hipFree(ol);
   return ZK_OK;
 }
 
 int zk_test_split_c8(zk_ctx* c, const float* x, int64_t n, int32_t w_exp, int32_t is_weight, uint16_t* out) {
   if (!c || !x || !out || n <= 0) return ZK_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  DevArena mem(c->stream);
   float* dx; half_t* dc;
-  HIPCHK(c, hipMalloc((void**)&dx, (size_t)n * 4)); HIPCHK(c, hipMalloc((void**)&dc, (size_t)n * 2));
+  HIPCHK(c, mem.alloc(&dx, (size_t)n * 4)); HIPCHK(c, mem.alloc(&dc, (size_t)n * 2));
   HIPCHK(c, hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
   zk_launch_split_c8(dx, n, w_exp, is_weight, dc, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(out, dc, (size_t)n * 2, hipMemcpyDeviceToHost));
-  (void)hipFree(dx); (void)hipFree(dc);
   return ZK_OK;
 }
 

@@ -340,6 +340,13 @@ class Context:
                                        out.ctypes.data, n_out), "zk_resample")
         return out
 
+    def resample_into(self, audio, n_in: int, orig_sr: int, new_sr: int, out):
+        """zk_resample on caller-provided buffers (numpy or device tensors); out holds ceil(new*n_in/orig) samples."""
+        pi, _k1 = _ptr(audio)
+        po, _k2 = _ptr(out)
+        self._chk(self.lib.zk_resample(self.h, pi, int(n_in), int(orig_sr), int(new_sr), po, int(out.shape[0])),
+                  "zk_resample")
+
     def wav_decode(self, raw: bytes, format_tag: int, bits: int, channels: int) -> np.ndarray:
         """sample bytes of a WAVE data chunk -> mono float32 (channel mean), decoded on the GPU"""
         buf = np.frombuffer(raw, dtype=np.uint8)

@@ -101,6 +101,13 @@ WEIGHT_SETS = {
     # per-output-row scales, LayerNorm gains with a handful of 4-8x outlier channels, and two "massive activation"
     # residual channels (fc2 biases of +55 / -40 in layers 2 and 3) that every later LayerNorm has to carry
     "heavy": dict(mat=0.03, bias=0.05, emb=0.05, gamma=0.25, beta=0.10, head=0.10, patch=0.05, heavy=True),
+    # INPUT-SENSITIVE: the three sets above see their input through a thick layer of input-independent terms (position
+    # embeddings, biases), so their logits move by only ~0.3-1 between very different windows and a front-end error
+    # would be attenuated before it reaches them.  Here the patch filters dominate the embedding (std 0.5 against 0.02
+    # for positions / cls), attention is content-peaked (std 0.07) and the head has 2x the gain: the six golden windows'
+    # logits span > 6 and, with the class-1 bias offset (centred for seed 31, the seed of tests/golden/model_sens.npz), their
+    # argmax (the stage-1 gate) flips between windows.
+    "sens": dict(mat=0.07, bias=0.02, emb=0.02, gamma=0.25, beta=0.05, head=0.20, patch=0.5, head_bias=(0.0, -5.5)),
 }
 MASSIVE_CHANNELS = ((47, 55.0), (512, -40.0))      # (residual channel, fc2 bias) of the "heavy" set
 MASSIVE_LAYERS = (2, 3)
@@ -151,6 +158,8 @@ def make_ast_weights(seed: int, weight_set: str = "wide", num_labels: int = NUM_
             out[name] = _tensor(seed, name, shape, ws["beta"])
         elif name.endswith(".bias"):
             out[name] = _tensor(seed, name, shape, ws["bias"])
+            if name == "classifier.dense.bias" and "head_bias" in ws:
+                out[name] = out[name] + np.asarray(ws["head_bias"], dtype=np.float32)[: shape[0]]
             if heavy and name.endswith("mlp.fc2.bias") and int(name.split(".layers.")[1].split(".")[0]) in MASSIVE_LAYERS:
                 for ch, val in MASSIVE_CHANNELS:
                     out[name][ch] = np.float32(val)
@@ -160,6 +169,7 @@ def make_ast_weights(seed: int, weight_set: str = "wide", num_labels: int = NUM_
             out[name] = _tensor(seed, name, shape, ws["patch"])
         elif name.startswith("classifier.dense"):
             out[name] = _tensor(seed, name, shape, ws["head"])
+
         elif heavy:
             out[name] = _heavy_matrix(seed, name, shape, ws["mat"])
         else:
