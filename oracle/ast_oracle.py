@@ -294,9 +294,13 @@ def encoder_layer(h: np.ndarray, L: dict, quant=None) -> np.ndarray:
     s = (_q(q, aq) @ _q(k, aq).transpose(0, 1, 3, 2)) * np.float32(HEAD_DIM ** -0.5)
     s = s - s.max(-1, keepdims=True)
     e = np.exp(s)
-    pr = e / e.sum(-1, keepdims=True)
     pq = "f16" if quant == "f16c8" else quant
-    a = (_q(pr, pq) @ _q(v, pq)).transpose(0, 2, 1, 3).reshape(B, S, HIDDEN)
+    if pq is None:
+        a = (e / e.sum(-1, keepdims=True)) @ v
+    else:       # what attention.hip computes: un-normalised weights rounded for the MFMA, row sum over the ROUNDED weights;
+        eq = _q(e, pq)      # v enters as (hi, lo) fp16 pair (P·Vh + P·Vl), i.e. to ~2^-22: unrounded here
+        a = (eq @ v) / eq.sum(-1, keepdims=True)
+    a = a.transpose(0, 2, 1, 3).reshape(B, S, HIDDEN)
     h = h + _lin(a, *L["o"], quant)
     x = _ln(h, *L["ln2"])
     m = _gelu(_lin(x, *L["fc1"], quant))

@@ -110,7 +110,7 @@ def _attn64(qkv, W):
     return (p @ v).transpose(0, 2, 1, 3).reshape(W * 1214, 768)
 
 
-@pytest.mark.parametrize("nsplit,tol", [(3, 6e-4), (2, 6e-4), (1, 2e-3)])
+@pytest.mark.parametrize("nsplit,tol", [(3, 2.5e-4), (2, 2.5e-4), (1, 2e-3)])      # measured 1.5e-4 / 1.4e-4 / 7.8e-4
 def test_attention(ctx, nsplit, tol):
     rng = np.random.default_rng(3)
     W = 2
@@ -119,7 +119,25 @@ def test_attention(ctx, nsplit, tol):
     out = ctx.test_attention(qkv, W, nsplit)
     ref = _attn64(qkv, W)
     err = np.abs(out - ref).max()
+    print(f"[attention] nsplit {nsplit}: max err / max|ref| = {err / np.abs(ref).max():.2e}")
     assert err <= tol * np.abs(ref).max(), err
+
+
+@pytest.mark.parametrize("nsplit", [3, 2])
+def test_attention_one_hot_rows_keep_v_precision(ctx, nsplit):
+    """Sharply peaked attention: a row's output IS (nearly) one v row, so v's own rounding is the output's error.  The
+    parity modes multiply P with v as an (hi, lo) fp16 pair (the Vl·P pass) and normalise with the sum of the ROUNDED
+    weights: measured 1.3e-4 of max|ref| (what remains is the fp16 rounding of the weights themselves on the rows that
+    are not quite one-hot); with v rounded to fp16 once — the build before round 3 — the same test sits at 3.9e-4."""
+    rng = np.random.default_rng(8)
+    qkv = rng.normal(0, 1.0, (1214, 2304)).astype(np.float32)
+    qkv[:, :768] *= 6.0                            # scores ~ N(0, 6^2): the row maximum carries almost all of the weight
+    qkv[:, 1536:] = (qkv[:, 1536:] * 3.0 + 5.0)    # v away from zero: relative rounding errors do not hide in small values
+    out = ctx.test_attention(qkv, 1, nsplit)
+    ref = _attn64(qkv, 1)
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    print(f"[attention one-hot rows] nsplit {nsplit}: max err / max|ref| = {err:.2e}")
+    assert err <= 2e-4, err
 
 
 @pytest.mark.parametrize("nsplit", [3, 2])

@@ -66,7 +66,8 @@ def test_feature_extractor_contract(G):
 def test_model_logits_and_checkpoints_vs_golden(G, tag, seed):
     from zkast import lib
     g, fb = G["model"], G["fbank"]
-    feats = orc.extract_features(__import__("zkast").synth.golden_windows()[[0, 1, 2, 4]], float(fb["mean"]),
+    from zkast import synth
+    feats = orc.extract_features(synth.golden_windows()[[0, 1, 2, 4]], float(fb["mean"]),
                                  float(fb["std"]))
     model, _ = _model(seed, tag, 0)
     ctx = lib.get_context(0)

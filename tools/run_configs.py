@@ -38,20 +38,35 @@ def main():
     from zkast import dist as zdist
     ctx = lib.get_context(device)
     gather = None
+    rccl_error = None
     if world > 1:
+        import torch
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         tdist.init_process_group("gloo", rank=rank, world_size=world)
         try:
             zdist.init_comm(ctx, rank, world)
-            gather = ctx.allgather_bytes
         except lib.ZkError as e:      # e.g. a rehearsal with several ranks on one GPU, which RCCL refuses
-            print(f"[run_configs] rank {rank}: RCCL communicator failed ({e}); host gathers over gloo instead", file=sys.stderr)
+            rccl_error = str(e)
+            print(f"[run_configs] rank {rank}: RCCL communicator failed ({e})", file=sys.stderr)
+        ok = torch.tensor([1 if ctx.comm_info()[1] == world else 0])      # every rank takes the same path (MIN over ranks)
+        tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)
+        if not bool(ok.item()):
+            if ctx.comm_info()[1] == world:
+                ctx.comm_destroy()
+            if os.environ.get("ZK_BENCH_REQUIRE_RCCL") == "1":
+                raise SystemExit(f"[run_configs] rank {rank}: ZK_BENCH_REQUIRE_RCCL=1 and no RCCL communicator over "
+                                 f"{world} ranks ({rccl_error or 'a peer failed'})")
+            print(f"[run_configs] rank {rank}: host gathers over gloo instead", file=sys.stderr)
 
             def gather(b):
                 box = [None] * world
                 tdist.all_gather_object(box, b)
                 return box
+        else:
+            gather = ctx.allgather_bytes
+    rccl_world = ctx.comm_info()[1] if (world > 1 and gather == ctx.allgather_bytes) else (1 if world == 1 else 0)
+    self_desc = {"rccl_world": rccl_world, "collective_fallback": bool(world > 1 and rccl_world != world)}
     S1, S2 = (-1.1509622, 3.5340312), (-6.5, 2.75)
     cas = np.load(os.path.join(ROOT, "tests", "golden", "cascade.npz"))
     sd1 = synth.make_ast_weights(21, "wide")
@@ -81,8 +96,11 @@ def main():
         s1, idx, s2 = casc(src)
         barrier()
         dt = time.perf_counter() - t0
+        mine = json.dumps({"rank": rank, "bytes_uploaded": int(casc.h2d_samples), "slices_uploaded": int(casc.uploads),
+                           "gather_s": round(casc.stats.get("gather_s", 0.0), 6)}).encode()
+        per_rank = [json.loads(b.decode()) for b in gather(mine)] if gather else [json.loads(mine.decode())]
         if rank == 0:
-            print(json.dumps({"config": "configs[3]: %.0f-min 48 kHz PCM16 recording, 1 s / 0.5 s-hop windows sharded over %d GPU(s)"
+            print(json.dumps({**self_desc, "per_rank": per_rank, "config": "configs[3]: %.0f-min 48 kHz PCM16 recording, 1 s / 0.5 s-hop windows sharded over %d GPU(s)"
                               % (minutes, world), "n_gpus": world, "windows": int(casc.n_windows), "gated_windows": int(len(idx)),
                               "seconds_end_to_end": dt, "windows_per_s": casc.n_windows / dt,
                               "file_bytes": len(pcm), "bytes_uploaded_by_rank0": int(casc.h2d_samples),
@@ -114,7 +132,7 @@ def main():
         if rank == 0:
             summary, rows = aggregate.aggregate(os.path.join(tmp, "out"), 0.5)
             nwin = sum(v["total_windows"] for v in summ.values())
-            print(json.dumps({"config": "configs[4]: %d synthetic patients x 2 files x %.0f min @16 kHz, patient-sharded over %d GPU(s), "
+            print(json.dumps({**self_desc, "config": "configs[4]: %d synthetic patients x 2 files x %.0f min @16 kHz, patient-sharded over %d GPU(s), "
                               "in-process batch driver + patient-level aggregation" % (args.patients, minutes, world),
                               "n_gpus": world, "patients_ok": sum(v == "ok" for v in st.values()), "windows": int(nwin),
                               "seconds_end_to_end": dt, "windows_per_s": nwin / dt,

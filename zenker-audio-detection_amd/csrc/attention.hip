@@ -55,7 +55,8 @@ constexpr int QKV_LD = 3 * ZK_HIDDEN;   // 2304
 constexpr int KT = 64;                  // keys per tile
 constexpr int NKT = (S_ + KT - 1) / KT; // 19
 #ifndef ZK_ATT_NW
-#define ZK_ATT_NW 4      // waves per workgroup (4: two workgroups per CU; 8: one, half the K/V staging per wave)
+#define ZK_ATT_NW 8      // waves per workgroup: 256 query rows share a K/V tile; ONE workgroup per CU (the split modes' four
+                         // images in 3-deep rings are 96 KiB), half the staging pieces per wave of the 4-wave form (same speed)
 #endif
 constexpr int NW = ZK_ATT_NW;
 constexpr int QT = 32 * NW;             // query rows per workgroup
@@ -64,10 +65,21 @@ constexpr int TILE_B = KT * 128;        // bytes of one [64][64] fp16 image
 template <int NSPLIT>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __restrict__ qkv_hi,
                                                         const half_t* __restrict__ qkv_lo, half_t* __restrict__ o_hi,
-                                                        half_t* __restrict__ o_lo, int n_windows, int q_tiles, int lo_fmt, int row_limit) {
+                                                        half_t* __restrict__ o_lo, int n_windows, int q_tiles, int lo_fmt, int row_limit, int rev) {
   constexpr bool SPLIT = (NSPLIT >= 2);
   constexpr bool C8 = (NSPLIT == 2);
-  constexpr int NIMG = SPLIT ? 3 : 2;     // Kh, [Kl | Kc8], V
+  // LDS images of one 64-key tile: K: Kh, [Kl | Kc8]; V: Vh, [Vl].  Vl = fp16(v - fp16(v)), the lo plane the QKV epilogue
+  // writes for v's columns: P·V = P·Vh + P·Vl.  v used to be the ONE operand of the whole network that reached an MFMA
+  // with plain fp16 rounding (2^-11; everything else carries a correction to ~2^-15+): harmless while attention averages
+  // over many keys, but on sharply peaked rows the output IS one v row and its rounding error goes straight into the
+  // residual stream (input-sensitive weight set: 1.2e-3 logit error, 0.4e-3 with v corrected).  The second PV pass adds no
+  // vector-ALU work (P is already there), only 8 MFMAs per tile on a pipe that was < 50 % busy.
+#ifdef ZK_ATT_NO_VL      // probe builds only: no Vl pass (timing / accuracy A-B)
+  constexpr bool VL = false;
+#else
+  constexpr bool VL = SPLIT;
+#endif
+  constexpr int NKIMG = SPLIT ? 2 : 1, NVIMG = VL ? 2 : 1, NIMG = NKIMG + NVIMG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   const int nwg = q_tiles * ZK_HEADS * n_windows;
   int wg;
   {
-    const int bid = blockIdx.x;
+    const int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;      // rev: last window first
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -130,7 +142,6 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   // A piece = one wave instruction = 8 rows x 128 B (1 KiB) of one image, lane -> (row = lane>>3, 16-B LDS chunk =
   // lane&7); the XOR swizzles of the images are applied on the SOURCE side (the DMA writes LDS lane-linearly).
   // A 64-key image has 8 pieces: wave w issues pieces w and w+4 (rows +32: same swizzle term).
-  constexpr int NKIMG = NIMG - 1;     // K images (Kh, [Kl | Kc8])
   constexpr int PPI = 8 / NW;             // pieces per image and wave: row blocks wave, wave + NW, ...
   constexpr int PER_ITER = PPI * NIMG;    // DMA instructions per wave and iteration
   unsigned koff[PPI], voff[PPI], koff_last[PPI], voff_last[PPI];
@@ -152,25 +163,25 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
     return (const char*)(((unsigned long long)hi << 32) | lo);
   };
-  // LDS: K ring = 3 x NKIMG images at 0, V ring = 3 images behind it
-  constexpr int KBUF_B = NKIMG * TILE_B;
+  // LDS: K ring = 3 x NKIMG images at 0, V ring = 3 x NVIMG images behind it
+  constexpr int KBUF_B = NKIMG * TILE_B, VBUF_B = NVIMG * TILE_B;
   constexpr int V_OFF = 3 * KBUF_B;
   auto dma = [&](const char* gbase, unsigned off, char* lds) __attribute__((always_inline)) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + off),
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
   };
-  // piece pc (0 .. PER_ITER-1) of the iteration's staging: K images of tile kt_k -> K slot sk (pieces 0 .. 2·NKIMG-1),
-  // V image of tile kt_v -> V slot sv.  Tiles are clamped to the last one: the surplus fetches of the final iterations
+  // piece pc (0 .. PER_ITER-1) of the iteration's staging: K images of tile kt_k -> K slot sk (pieces 0 .. PPI·NKIMG-1),
+  // V images of tile kt_v -> V slot sv.  Tiles are clamped to the last one: the surplus fetches of the final iterations
   // land in dead slots.
   auto dma_piece = [&](int pc, int kt_k, int sk, int kt_v, int sv) __attribute__((always_inline)) {
     const bool isk = pc < PPI * NKIMG;
     int kt = isk ? kt_k : kt_v;
     kt = kt < NKT - 1 ? kt : NKT - 1;
     const bool last = kt == NKT - 1;
-    const int u = pc % PPI, img = isk ? pc / PPI : 0;
+    const int u = pc % PPI, img = isk ? pc / PPI : pc / PPI - NKIMG;      // image 0 = hi plane, 1 = lo plane
     const size_t tb = ((tok0 + (size_t)kt * KT) * QKV_LD + head * ZK_HEAD_DIM) * 2;     // bytes
     const char* src = (img == 1 ? (const char*)qkv_lo : (const char*)qkv_hi) + tb + (isk ? 1 : 2) * ZK_HIDDEN * 2;
-    char* base = isk ? smem + sk * KBUF_B + img * TILE_B : smem + V_OFF + sv * TILE_B;
+    char* base = isk ? smem + sk * KBUF_B + img * TILE_B : smem + V_OFF + sv * VBUF_B + img * TILE_B;
     const unsigned o = isk ? (last ? koff_last[u] : koff[u]) : (last ? voff_last[u] : voff[u]);
     dma(uniform_ptr(src), o, base + (wave + NW * u) * 1024);
   };
@@ -205,10 +216,12 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   // LDS round trip, and the softmax after them).
   //   score slots (tile t+1):  C8: per 32-key block 2 fp8 groups (1 MFMA, 64 cycles, 4 exps) + 4 fp16 groups (1 MFMA,
   //                            32 cycles, 2 exps); X3: 8 groups of 3 MFMAs, 4 exps; F16: 8 groups of 1 MFMA, 4 exps
-  //   PV slots (tile t):       8 groups of 1 MFMA + 4 elements of the next tile's row maximum
+  //   PV slots (tile t):       8 groups (split modes: 16, Vh and Vl alternating) of 1 MFMA + 4 (2) elements of the next
+  //                            tile's row maximum
   struct kf_t { i4v_t a, b; };
   constexpr int NG_QK = C8 ? 12 : 8;
-  constexpr int NSLOT = NG_QK + 8;
+  constexpr int NG_PV = VL ? 16 : 8;      // split modes: every V fragment twice, from the Vh and the Vl image
+  constexpr int NSLOT = NG_QK + NG_PV;
 #ifndef ZK_ATT_LA
 #define ZK_ATT_LA 4
 #endif
@@ -231,6 +244,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   auto reads_after = [nreads](int g) constexpr {
     int n = 0;
     for (int j = g + 1; j <= g + LA && j < NSLOT; ++j) n += nreads(j);
+    static_assert(LA * 2 + 2 <= 15, "lgkmcnt is a 4-bit counter");
     return n;
   };
   auto load_group = [&](auto gc) __attribute__((always_inline)) {
@@ -254,10 +268,13 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
           asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a) : "v"(ka[ks]), "n"(kb * 4096));
       }
     } else {
-      constexpr int v = g - NG_QK, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
+      // PV group: fragment (kb, sx, mb) of the Vh image — split modes: groups alternate Vh / Vl (image offset TILE_B)
+      constexpr int pv = g - NG_QK, v = VL ? pv / 2 : pv, img = VL ? pv % 2 : 0;
+      constexpr int kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
       i2v_t t0, t1;
       asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-                   : "=&v"(t0), "=&v"(t1) : "v"(va[mb]), "n"((kb * 32 + 16 * sx) * 128), "n"((kb * 32 + 16 * sx + 8) * 128));
+                   : "=&v"(t0), "=&v"(t1) : "v"(va[mb]), "n"((kb * 32 + 16 * sx) * 128 + img * TILE_B),
+                     "n"((kb * 32 + 16 * sx + 8) * 128 + img * TILE_B));
       f.a = __builtin_shufflevector(t0, t1, 0, 1, 2, 3);
     }
   };
@@ -333,6 +350,27 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     l_run *= alpha;
   };
 
+  // Two probabilities p = 2^score of this lane's row: rounded to fp16 for the P·V MFMA, and the row sum l accumulates
+  // the ROUNDED values, not the fp32 ones.  O / l is then an exactly normalised average with
+  // weights fp16(p): a weight's rounding error enters as δ·p·(v − O) instead of δ·p·v, which vanishes for the sharply
+  // peaked rows where one key carries the sum (measured on the input-sensitive weight set: logit error -28 %).
+  auto exp_pair = [&](f16_t (&sc)[2], h8_t (&pf)[2][2], int e, float acc) __attribute__((always_inline)) {
+#if ZK_ATT_ABL & 4
+    const float p0 = sc[e >> 4][e & 15], p1 = sc[e >> 4][(e & 15) + 1];
+#else
+    const float p0 = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15]), p1 = __builtin_amdgcn_exp2f(sc[e >> 4][(e & 15) + 1]);
+#endif
+    const h2_t pr = {(half_t)p0, (half_t)p1};
+    pf[e >> 4][(e & 15) >> 3][e & 7] = pr[0];
+    pf[e >> 4][(e & 15) >> 3][(e & 7) + 1] = pr[1];
+    // acc += fp16 halves of pr, exactly, as two v_fma_mix_f32 (fp16 source operands read in place: the same instruction
+    // count as the fp32 adds they replace; v_dot2_f32_f16 would be one instruction but measured +5 % on the kernel)
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pr), "v"(acc));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(pr), "v"(r));
+    return acc;
+  };
+
   f16_t sA[2], sB[2];
   float mx = 0.f;
   if (wave_active) {      // scores of tile 0 (no overlap partner yet)
@@ -378,7 +416,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) ka[ks] = kofs[ks] + (unsigned)(s1 * KBUF_B);      // K(t+1)
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) va[mb] = vofs[mb] + (unsigned)(s0 * TILE_B);       // V(t)
+    for (int mb = 0; mb < 2; ++mb) va[mb] = vofs[mb] + (unsigned)(s0 * VBUF_B);       // V(t)
 
     if (wave_active) {
       // deferred rescale (rare, wave-uniform): before the next tile's scores are started with the running max
@@ -393,11 +431,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       });
       if constexpr (LAST) {      // nothing to overlap the exponentials with
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-          const float p = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15]);
-          psum += p;
-          pf[e >> 4][(e & 15) >> 3][e & 7] = (half_t)p;
-        }
+        for (int e = 0; e < 32; e += 2) psum = exp_pair(sc, pf, e, psum);
       }
       __builtin_amdgcn_sched_barrier(0);
       static_for<NSLOT - G0>([&](auto ic) __attribute__((always_inline)) {
@@ -408,22 +442,15 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
         if constexpr (g < NG_QK) {
           mma_group(std::integral_constant<int, g>{}, sn);
 #pragma unroll
-          for (int e = exp_first(g); e < exp_first(g) + exp_count(g); ++e) {
-#if ZK_ATT_ABL & 4
-            const float p = sc[e >> 4][e & 15];
-#else
-            const float p = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15]);
-#endif
-            psum += p;
-            pf[e >> 4][(e & 15) >> 3][e & 7] = (half_t)p;
-          }
+          for (int e = exp_first(g); e < exp_first(g) + exp_count(g); e += 2) psum = exp_pair(sc, pf, e, psum);
         } else {
-          constexpr int v = g - NG_QK, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
+          constexpr int pv = g - NG_QK, v = VL ? pv / 2 : pv, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
+          constexpr int EPS = 32 / NG_PV;      // elements of the next tile's row maximum per PV slot
           oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[g % (LA + 1)].a), pf[kb][sx],
-                                                            oacc[mb], 0, 0, 0);
+                                                            oacc[mb], 0, 0, 0);      // (split modes: Vh·P, then Vl·P)
           if constexpr (!LAST) {
 #pragma unroll
-            for (int e = 4 * v; e < 4 * v + 4; ++e) {
+            for (int e = EPS * pv; e < EPS * pv + EPS; ++e) {
               constexpr int dummy = 0; (void)dummy;
               const int kbn = e >> 4, r = e & 15;
               if constexpr (MASKNEXT) {
@@ -515,7 +542,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
 
 }  // namespace
 
-void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit, int q_tiles, hipStream_t s) {
+void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit, int q_tiles, hipStream_t s, int rev) {
   if (n_windows <= 0) return;
   // q_tiles counts 128-row query blocks (< 10: only the first q_tiles*128 query rows, the last layer's pruning); the
   // kernel's workgroup covers QT = 32·NW rows, waves beyond the row limit only help staging
@@ -529,9 +556,14 @@ void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit
       (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr[nsplit & 3] = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * NW), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, wg_tiles, out.lo_fmt, row_limit);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * NW), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, wg_tiles, out.lo_fmt, row_limit, rev);
   };
-  if (nsplit == 2) go(attention_kernel<2>, 3 * 3 * TILE_B);
-  else if (nsplit == 3) go(attention_kernel<3>, 3 * 3 * TILE_B);
+#ifdef ZK_ATT_NO_VL
+  constexpr int NIMG_SPLIT = 3;
+#else
+  constexpr int NIMG_SPLIT = 4;
+#endif
+  if (nsplit == 2) go(attention_kernel<2>, 3 * NIMG_SPLIT * TILE_B);
+  else if (nsplit == 3) go(attention_kernel<3>, 3 * NIMG_SPLIT * TILE_B);
   else go(attention_kernel<1>, 3 * 2 * TILE_B);
 }

@@ -15,10 +15,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t row_stride,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int rows, half_t* o_hi,
-                                                        half_t* o_lo, int lo_fmt, int32_t* rowexp, float eps) {
+                                                        half_t* o_lo, int lo_fmt, int32_t* rowexp, float eps, int rev) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (rev) row = rows - 1 - row;
   const float* xr = x + (size_t)row * row_stride;
   f4_t v[3];
 #pragma unroll
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }  // namespace
 
 void zk_launch_layernorm(const float* x, int64_t row_stride, const float* gamma, const float* beta, int rows,
-                         zk_planes out, float eps, hipStream_t s) {
+                         zk_planes out, float eps, hipStream_t s, int rev) {
   if (rows <= 0) return;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, gamma, beta, rows,
-                     out.hi, out.lo, out.lo_fmt, (out.lo && out.lo_fmt == ZK_LO_C8) ? out.rowexp : nullptr, eps);
+                     out.hi, out.lo, out.lo_fmt, (out.lo && out.lo_fmt == ZK_LO_C8) ? out.rowexp : nullptr, eps, rev);
 }

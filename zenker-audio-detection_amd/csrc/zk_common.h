@@ -101,15 +101,19 @@ struct zk_gemm_args {
   float* resid;        // [M, N] fp32, in-place += (RESID) ; PATCH: hidden base
   const float* pos;    // PATCH: position embeddings [1214, 768]
   int lo_n_limit;      // STORE: write the lo plane only for n < lo_n_limit
-  int lo_c8_from;      // STORE (ZK_F16C8): columns lo_c8_from <= n < lo_n_limit get a c8 lo plane (k of the fused QKV), the rest fp16
+  int lo_c8_from;      // STORE (ZK_F16C8): columns lo_c8_from <= n < min(lo_c8_to, lo_n_limit) get a c8 lo plane (k of the fused
+  int lo_c8_to = 1 << 30;   //   QKV: the fp8-corrected QK^T), the others an fp16 lo plane (q: re-split by attention; v: the Vl·P pass)
   int w_exp;           // ZK_F16C8: the weight's c8 plane holds (fp8(W·2^w_exp), fp8((W-Wh)·2^(w_exp+11)))
+  int rev = 0;         // ZK_F16C8: walk the row blocks from the last to the first (same results, other order)
 };
 
 // launchers (each file owns its kernels)
 void zk_launch_gemm(const zk_gemm_args& a, int epi, int nsplit, hipStream_t s);
+// rev (LayerNorm, attention, zk_gemm_args::rev): process the rows from the last to the first — same results; lets a
+// kernel start on what its producer wrote last (zkast.hip: walk alternation)
 void zk_launch_layernorm(const float* x, int64_t row_stride, const float* gamma, const float* beta, int rows,
-                         zk_planes out, float eps, hipStream_t s);
-void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit, int q_tiles, hipStream_t s);
+                         zk_planes out, float eps, hipStream_t s, int rev = 0);
+void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit, int q_tiles, hipStream_t s, int rev = 0);
 void zk_launch_gather_tok01(zk_planes att, const float* hidden, int n_windows, zk_planes att_out, float* hidden_out,
                             hipStream_t s);
 void zk_launch_im2col_compact(const float* feats, int n_frames, const int32_t* win_idx, int n_windows, float mean,

@@ -108,6 +108,11 @@ struct zk_ctx {
   hipStream_t stream = nullptr;
   bool async = false;
   int micro_batch = 0;   // 0 = auto
+  // Walk alternation (ZK_WALK_ALT=1 in the environment at zk_create): consecutive kernels of a layer process the token rows
+  // in opposite directions, so each starts on the rows its producer wrote last (the tail of a 2-15 GB plane that may
+  // still be in the 256 MiB Infinity Cache) instead of the rows that left the caches first.  Results are identical.
+  bool walk_alt = false;
+  int walk_dir = 0;
   std::string err;
   StageModel model[2];
 
@@ -372,8 +377,17 @@ int ensure_workspace(zk_ctx* c, int windows, bool split) {
   return ZK_OK;
 }
 
+// direction of the next kernel of the chain (0 = first row first); flips with every call while walk_alt is on
+int next_dir(zk_ctx* c) {
+  if (!c->walk_alt) return 0;
+  const int d = c->walk_dir;
+  c->walk_dir ^= 1;
+  return d;
+}
+
 void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, int M, int N, int K, int epi, int nsplit,
-              zk_planes out, float* resid, const float* pos, int lo_n_limit, int lo_c8_from = 1 << 30) {
+              zk_planes out, float* resid, const float* pos, int lo_n_limit, int lo_c8_from = 1 << 30, int rev = 0,
+              int lo_c8_to = 1 << 30) {
   ProfScope ps(c, cls);
   if (c->prof) c->prof_flops[cls] += 2.0 * M * (double)N * K;
   zk_gemm_args a;
@@ -381,7 +395,8 @@ void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias,
   a.x_rowexp = (nsplit == ZK_F16C8) ? x.rowexp : nullptr;
   a.M = M; a.N = N; a.K = K;
   a.o_hi = out.hi; a.o_lo = (nsplit != ZK_F16) ? out.lo : nullptr;
-  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.lo_c8_from = lo_c8_from; a.w_exp = w.exp;
+  a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.lo_c8_from = lo_c8_from; a.lo_c8_to = lo_c8_to; a.w_exp = w.exp;
+  a.rev = rev;
   if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
   else zk_launch_gemm(a, epi, nsplit, c->stream);
 }
@@ -408,20 +423,23 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
     c->tap_windows = nb;
   }
   bool pruned = false;
+  c->walk_dir = 1;      // the patch GEMM above walked forwards: the first LayerNorm starts from the end
   for (int l = 0; l < sm.n_layers; ++l) {
     const LayerW& L = sm.L[l];
     // Only tokens 0/1 reach the head (ASTModel.forward:304), so in the LAST layer the queries, the attention output
     // projection and the MLP are needed for those two rows only (exact: same arithmetic per row).  K/V still need every
     // token.  Disabled while a debug tap wants the full residual stream of that layer.
     const bool last = (l == sm.n_layers - 1) && c->prune_last && c->tap_layer != l;
-    { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, M, xn, sm.eps, c->stream); }
+    { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, M, xn, sm.eps, c->stream, next_dir(c)); }
+    // lo planes of the fused QKV: q fp16 (re-split by attention), k c8 byte pairs in ZK_F16C8 (fp8-corrected QK^T) else
+    // fp16, v fp16 (attention's Vl·P pass)
     run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, M, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv,
-             nullptr, nullptr, 2 * ZK_HIDDEN, ns == ZK_F16C8 ? ZK_HIDDEN : 1 << 30);      // (c8: k's lo plane is c8)
+             nullptr, nullptr, 3 * ZK_HIDDEN, ns == ZK_F16C8 ? ZK_HIDDEN : 1 << 30, next_dir(c), 2 * ZK_HIDDEN);
     {
       ProfScope ps(c, P_ATTN);
       const int qt = last ? 1 : 10;
       if (c->prof) c->prof_flops[P_ATTN] += (double)nb * ZK_HEADS * 4.0 * (qt == 1 ? 128.0 : (double)ZK_SEQ) * ZK_SEQ * ZK_HEAD_DIM;
-      zk_launch_attention(qkv, att, nb, ns == ZK_F16C8 ? 2 : (sp ? 3 : 1), qt, c->stream);
+      zk_launch_attention(qkv, att, nb, ns == ZK_F16C8 ? 2 : (sp ? 3 : 1), qt, c->stream, next_dir(c));
     }
     if (last) {
       zk_planes att_s = c->att_s.get(sp, lf), xn_s = c->xn_s.get(sp, lf), mid_s = c->mid_s.get(sp, lf);
@@ -438,12 +456,12 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
       continue;
     }
     run_gemm(c, P_GEMM_O, att, L.wo, L.bo, M, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
-             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0);
-    { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln2_g, L.ln2_b, M, xn, sm.eps, c->stream); }
+             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c));
+    { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln2_g, L.ln2_b, M, xn, sm.eps, c->stream, next_dir(c)); }
     run_gemm(c, P_GEMM_FC1, xn, L.w1, L.b1, M, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid, nullptr, nullptr,
-             ZK_INTER);
+             ZK_INTER, 1 << 30, next_dir(c));
     run_gemm(c, P_GEMM_FC2, mid, L.w2, L.b2, M, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
-             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0);
+             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c));
     if (c->tap_layer == l) {
       HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
       HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -561,6 +579,7 @@ int zk_create(int device_id, zk_ctx** out) {
   }
   if (device_id < 0 || device_id >= n) return fail(nullptr, ZK_E_ARG, "device_id %d out of range [0,%d)", device_id, n);
   zk_ctx* c = new zk_ctx();
+  if (const char* wa = getenv("ZK_WALK_ALT")) c->walk_alt = wa[0] == '1';
   c->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess) { delete c; return fail(nullptr, ZK_E_HIP, "hipSetDevice(%d) failed", device_id); }
   hipDeviceProp_t prop;

@@ -102,18 +102,30 @@ def gate_indices(s1_probs: np.ndarray, thr1: float, fwd_min_prob: Optional[float
 
 def sharded_cascade(n_windows: int, stage_logits: Callable[[int, np.ndarray], np.ndarray], rank: int, world: int,
                     thr1: float, fwd_min_prob: Optional[float] = None, device=None,
-                    softmax: Callable[[np.ndarray], np.ndarray] = softmax_np, ctx=None):
+                    softmax: Callable[[np.ndarray], np.ndarray] = softmax_np, ctx=None, stats: Optional[dict] = None):
     """stage_logits(stage, win_idx int32[]) -> (len(win_idx), 2) logits of those windows, computed locally.
-    Returns (s1_logits (N,2), swallow_idx (K,), s2_logits (K,2)) — identical on every rank."""
+    Returns (s1_logits (N,2), swallow_idx (K,), s2_logits (K,2)) — identical on every rank.
+    stats (optional dict): "gather_s" += wall time of the two logit all-gathers (includes waiting for the slowest rank),
+    "gathers" += their count."""
+    import time
+
+    def gather(local, total):
+        t0 = time.perf_counter()
+        out = all_gather_rows(local, total, world, device, ctx)
+        if stats is not None:
+            stats["gather_s"] = stats.get("gather_s", 0.0) + (time.perf_counter() - t0)
+            stats["gathers"] = stats.get("gathers", 0) + 1
+        return out
+
     lo, hi = shard_range(n_windows, rank, world)
     mine = np.arange(lo, hi, dtype=np.int32)
     l1 = stage_logits(0, mine) if hi > lo else np.zeros((0, 2), np.float32)
-    s1 = all_gather_rows(l1, n_windows, world, device, ctx)
+    s1 = gather(l1, n_windows)
     idx = gate_indices(softmax(s1) if n_windows else np.zeros((0, 2), np.float32), thr1, fwd_min_prob)
     k = int(idx.shape[0])
     klo, khi = shard_range(k, rank, world)
     l2 = stage_logits(1, idx[klo:khi]) if khi > klo else np.zeros((0, 2), np.float32)
-    s2 = all_gather_rows(l2, k, world, device, ctx) if k else np.zeros((0, 2), np.float32)
+    s2 = gather(l2, k) if k else np.zeros((0, 2), np.float32)
     return s1, idx, s2
 
 
@@ -167,6 +179,8 @@ class ZkShardedCascade:
             use_ctx_comm = ctx.comm_info()[1] == world and world > 1
         self.comm_ctx = ctx if use_ctx_comm else None
         self.h2d_samples = 0          # audio samples (array) or bytes (WavSource) uploaded by the last call
+        self.uploads = 0              # slices uploaded by the last call (1 = stage 2 stayed inside the stage-1 slice)
+        self.stats = {}               # gather_s / gathers of the last call (sharded_cascade)
         self.n_windows = 0
 
     def __call__(self, audio, window_sec=1.0, hop_sec=0.5, thr1=0.5, fwd_min_prob=None):
@@ -181,11 +195,14 @@ class ZkShardedCascade:
         for m, fx in zip(self.m, self.fx):
             m.bind_feature_extractor(fx)
         self.h2d_samples = 0
+        self.uploads = 0
+        self.stats = {}
         slot = [0, 0]                 # window range [lo, hi) currently in the feature slot
 
         def fill_slot(lo, hi):
             if lo >= slot[0] and hi <= slot[1]:
                 return
+            self.uploads += 1
             a0 = lo * hop
             a1 = min(n_samples, (hi - 1) * hop + win)      # a recording shorter than one window is zero-padded
             if src is not None:
@@ -204,4 +221,4 @@ class ZkShardedCascade:
             return self.m[stage].forward_from_slot(len(win_idx), win_idx - np.int32(slot[0]))
 
         return sharded_cascade(n, stage_logits, self.rank, self.world, thr1, fwd_min_prob, self.device, ctx.softmax,
-                               self.comm_ctx)
+                               self.comm_ctx, self.stats)
