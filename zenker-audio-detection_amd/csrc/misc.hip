@@ -129,19 +129,27 @@ __global__ __launch_bounds__(256) void wav_decode_kernel(const unsigned char* __
 // (torchaudio.functional._apply_sinc_resample_kernel: conv1d with stride=orig over the padded waveform).
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, int64_t n_in, int orig, int neu,
                                                        int width, const float* __restrict__ kernels, int klen,
-                                                       float* __restrict__ out, int64_t n_out) {
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                       float* __restrict__ out, int64_t n_out, int span) {
+  // A block's 256 consecutive outputs read one contiguous stretch of the input (frames i0 .. i1 of `orig` samples plus the
+  // kernel's reach): it is staged ONCE into LDS with coalesced loads — the per-output reads are `orig` apart across the
+  // lanes and overlap klen-fold — zeros outside the recording (the conv1d's padding).  The taps of the <= neu phases stay
+  // in L1 (one broadcast address per phase).  Same accumulation order as before the staging: bit-identical outputs.
+  extern __shared__ float tile[];
+  const int64_t o0 = (int64_t)blockIdx.x * 256;
+  const int64_t s0 = (o0 / neu) * orig - width;            // first input sample the block can touch
+  for (int t = threadIdx.x; t < span; t += 256) {
+    const int64_t sidx = s0 + t;
+    tile[t] = (sidx >= 0 && sidx < n_in) ? in[sidx] : 0.f;
+  }
+  __syncthreads();
+  const int64_t o = o0 + threadIdx.x;
   if (o >= n_out) return;
   const int64_t i = o / neu;
   const int p = (int)(o - i * neu);
   const float* kr = kernels + (size_t)p * klen;
-  const int64_t base = i * orig - width;
+  const float* x = tile + (int)(i * orig - width - s0);
   float acc = 0.f;
-  for (int j = 0; j < klen; ++j) {
-    const int64_t s = base + j;
-    const float x = (s >= 0 && s < n_in) ? in[s] : 0.f;
-    acc = fmaf(kr[j], x, acc);
-  }
+  for (int j = 0; j < klen; ++j) acc = fmaf(kr[j], x[j], acc);
   out[o] = acc;
 }
 
@@ -156,8 +164,9 @@ void zk_launch_split_f32(const float* src, int64_t n, float scale, half_t* hi, h
 void zk_launch_resample(const float* in, int64_t n_in, int orig, int neu, int width, const float* kernels, int klen,
                         float* out, int64_t n_out, hipStream_t s) {
   if (n_out <= 0) return;
-  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, in, n_in, orig, neu,
-                     width, kernels, klen, out, n_out);
+  const int span = (255 / neu + 1) * orig + klen;      // input samples 256 consecutive outputs can reach
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), (size_t)span * 4, s, in, n_in, orig,
+                     neu, width, kernels, klen, out, n_out, span);
 }
 
 void zk_launch_split_rows_c8(const float* src, int rows, int K, half_t* hi, half_t* c8, int32_t* rowexp, hipStream_t s) {

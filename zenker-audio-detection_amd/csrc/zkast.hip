@@ -992,6 +992,10 @@ int zk_resample(zk_ctx* c, const float* in, int64_t n_in, int32_t orig_sr, int32
     const double base_freq = (double)(orig < neu ? orig : neu) * rolloff;
     const int width = (int)ceil(lpw * orig / base_freq);
     const int klen = 2 * width + orig;
+    // the kernel stages the input stretch of 256 outputs in LDS (zk_launch_resample): every pair of standard audio rates
+    // fits (44.1 -> 16 kHz: 5.4 KB); a ratio whose reduced period runs into the tens of thousands does not
+    if (((int64_t)(255 / neu + 1) * orig + klen) * 4 > 60 * 1024)
+      return fail(c, ZK_E_SHAPE, "resampling %d -> %d Hz (period %d : %d) is not supported", orig_sr, new_sr, orig, neu);
     std::vector<float> k((size_t)neu * klen);
     for (int p = 0; p < neu; ++p)
       for (int j = 0; j < klen; ++j) {
