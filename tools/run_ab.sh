@@ -1,3 +1,6 @@
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -q -s -k "attention" > gpurun_out/r3f_attn_tests.log 2>&1
-timeout -k 10 400 python tools/attn_ab_multi.py 512 5 qb1,base,qb2acc > gpurun_out/r3f_attn_ab.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r3h_gpu_tests.log 2>&1
+timeout -k 10 900 bash tools/profile_round.sh r03 > gpurun_out/r3h_profile.log 2>&1
+timeout -k 10 900 python bench.py --steps 20 --warmup 1 > gpurun_out/r3h_bench20.json 2> gpurun_out/r3h_bench20.err
+timeout -k 10 300 python tools/run_configs.py --config 3 > gpurun_out/r3h_cfg3.json 2> gpurun_out/r3h_cfg3.err
+timeout -k 10 300 python tools/run_configs.py --config 4 > gpurun_out/r3h_cfg4.json 2> gpurun_out/r3h_cfg4.err
