@@ -28,7 +28,10 @@ def _worker(rank, world, port, n, thr, q):
         calls.append((stage, np.asarray(idx).copy()))
         return _fake_logits(stage, idx)
 
-    s1, idx, s2 = zdist.sharded_cascade(n, stage_logits, rank, world, thr, None)
+    stats = {}
+    s1, idx, s2 = zdist.sharded_cascade(n, stage_logits, rank, world, thr, None, stats=stats)
+    # two gathers when something passed the gate, one otherwise; their wall time is what tools/run_configs.py reports per rank
+    assert stats["gathers"] == (2 if len(idx) else 1) and stats["gather_s"] > 0.0
     q.put((rank, s1, idx, s2, [(s, i.tolist()) for s, i in calls]))
     dist.barrier()
     dist.destroy_process_group()

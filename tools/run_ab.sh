@@ -1,6 +1,4 @@
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r3h_gpu_tests.log 2>&1
-timeout -k 10 900 bash tools/profile_round.sh r03 > gpurun_out/r3h_profile.log 2>&1
-timeout -k 10 900 python bench.py --steps 20 --warmup 1 > gpurun_out/r3h_bench20.json 2> gpurun_out/r3h_bench20.err
-timeout -k 10 300 python tools/run_configs.py --config 3 > gpurun_out/r3h_cfg3.json 2> gpurun_out/r3h_cfg3.err
-timeout -k 10 300 python tools/run_configs.py --config 4 > gpurun_out/r3h_cfg4.json 2> gpurun_out/r3h_cfg4.err
+for mb in 0 341 256 171 128 107 64 35 17 8; do
+timeout -k 10 200 python bench.py --headline-only --steps 3 --micro-batch $mb > gpurun_out/r3i_mb_$mb.json 2> gpurun_out/r3i_mb_$mb.err
+done
