@@ -9,7 +9,9 @@
 Workload (config.workload): BASELINE.json configs[2] — batch of 1024 synthetic 1 s / 0.5 s-hop windows per GPU, cut on
 the device from one resident 16 kHz recording.  A step = ONE call of the product's cascade entry point `zk_two_stage`
 (log-mel of the 1024 windows, stage-1 forward, on-device gate + compaction, the host sync that sizes stage 2, stage-2
-forward on the gated windows) with device-resident inputs and outputs, plus — when N > 1 — the RCCL all-gather of both
+forward on the gated windows) on the recording resident in HBM (the context's audio slot, put there once by the product's
+own `zk_audio_load`) with the logits and the gate list returned into host arrays (20 KB per step), plus — when N > 1 — the
+RCCL all-gather of both
 logit tables through the C ABI (`zk_allgather_logits`; torch.distributed only ships the 128-byte RCCL id at start-up).
 
 Gate rate g (SURVEY.md §8d knob): random weights give arbitrary gating, so the stage-1 classifier bias is shifted until
@@ -120,21 +122,26 @@ def main():
     hop, win = 8000, 16000
     n_samples = win + (B - 1) * hop
     rec = synth.synth_recording(100 + rank, n_samples)
-    audio = torch.from_numpy(rec).to(dev)                       # inputs resident in HBM before the timed region
-    s1_logits = torch.empty((B, 2), dtype=torch.float32, device=dev)
-    s2_logits = torch.zeros((B, 2), dtype=torch.float32, device=dev)
-    sw_idx = torch.empty((B,), dtype=torch.int32, device=dev)
-    sw_cnt = torch.zeros((4,), dtype=torch.int32, device=dev)
+    # Inputs resident in HBM before the timed region, through the product's own load_audio entry point: the recording
+    # goes up ONCE into the context's audio slot (zk_audio_load; IEEE-float samples, already 16 kHz) and every step reads
+    # it there (audio = NULL).  Outputs are plain host arrays filled through the C ABI (16 KB of logits + the gate list
+    # per step); no torch tensor takes part in a step.
+    assert ctx.audio_load(rec.tobytes(), 3, 32, 1, 16000, 16000) == n_samples
+    audio = None
+    s1_logits = np.empty((B, 2), dtype=np.float32)
+    s2_logits = np.zeros((B, 2), dtype=np.float32)
+    sw_idx = np.empty((B,), dtype=np.int32)
+    sw_cnt = np.zeros((4,), dtype=np.int32)
     if world > 1:
-        g1 = torch.empty((world, B, 2), dtype=torch.float32, device=dev)
-        g2 = torch.empty((world, B, 2), dtype=torch.float32, device=dev)
+        g1 = np.empty((world, B, 2), dtype=np.float32)
+        g2 = np.empty((world, B, 2), dtype=np.float32)
 
     # ---- calibration (untimed): shift the stage-1 "swallow" bias so that every window passes the argmax test ----
     m1 = ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd1, stage=0, compute_mode=args.mode,
                                      device=local_rank, fx_mean=S1[0], fx_std=S1[1])
     ctx.logmel(audio, n_samples, 0, hop, win, B)
     ctx.ast_forward(0, None, None, B, s1_logits)
-    l = s1_logits.cpu().numpy()
+    l = s1_logits
     shift = float(-(l[:, 1] - l[:, 0]).min() + 0.05)
     sd1s = dict(sd1)
     sd1s["classifier.dense.bias"] = sd1["classifier.dense.bias"].copy()
@@ -144,7 +151,7 @@ def main():
     m2 = ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd2, stage=1, compute_mode=args.mode,
                                      device=local_rank, fx_mean=S2[0], fx_std=S2[1])
     ctx.ast_forward(0, None, None, B, s1_logits)
-    p_sw = torch.softmax(s1_logits, dim=1)[:, 1].cpu().numpy().astype(np.float32)
+    p_sw = ctx.softmax(s1_logits)[:, 1].astype(np.float32)
     assert (p_sw > 0.5).all()
 
     def thr_for(g):      # the cascade's own gate threshold that lets the top-g fraction through
@@ -160,11 +167,10 @@ def main():
             ctx.allgather_logits(s1_logits, B, 2, g1)
             ctx.allgather_logits(s2_logits, B, 2, g2)
         elif world > 1:
-            h1, h2 = s1_logits.cpu(), s2_logits.cpu()
             o1, o2 = torch.empty((world * B, 2)), torch.empty((world * B, 2))
-            tdist.all_gather_into_tensor(o1, h1)
-            tdist.all_gather_into_tensor(o2, h2)
-            g1.copy_(o1.view(world, B, 2)); g2.copy_(o2.view(world, B, 2))
+            tdist.all_gather_into_tensor(o1, torch.from_numpy(s1_logits))
+            tdist.all_gather_into_tensor(o2, torch.from_numpy(s2_logits))
+            g1[:] = o1.view(world, B, 2).numpy(); g2[:] = o2.view(world, B, 2).numpy()
 
     def gather_bytes(b):
         if use_rccl:
@@ -174,7 +180,6 @@ def main():
         return box
 
     def barrier():
-        torch.cuda.synchronize()
         ctx.synchronize()
         if world > 1:
             gather_bytes(b"\0")
@@ -199,7 +204,7 @@ def main():
         return max_over_ranks(dt), prof
 
     dt, prof = timed(args.steps, args.warmup, profile=True)
-    K = int(sw_cnt.cpu().numpy()[0])
+    K = int(sw_cnt[0])
     windows = world * B * args.steps
     value = windows / dt
 
@@ -249,7 +254,7 @@ def main():
         "metric": "1-s audio windows/sec two-stage (mel+ASTx2)", "value": value, "unit": "windows/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
-        "config": {"workload": "configs[2]: full two-stage cascade (zk_two_stage), batch=1024 1-s windows per GPU, hop "
+        "config": {"workload": f"configs[2]: full two-stage cascade (zk_two_stage), batch={B} 1-s windows per GPU, hop "
                                f"0.5 s, gate rate g={K / B:.2f}", "windows_per_gpu": B, "stage2_windows_per_gpu": K,
                    "micro_batch": args.micro_batch, "weights": "synthetic splitmix64 'wide' set (seeds 21/22), stage-1 "
                    f"swallow bias shifted by {shift:+.3f} so that thr1 alone sets the gate rate",
@@ -273,7 +278,7 @@ def main():
         for g in (0.5, 0.1):
             state["thr"], _k = thr_for(g)
             dts, _ = timed(nsw, 1)
-            kk = int(sw_cnt.cpu().numpy()[0])
+            kk = int(sw_cnt[0])
             sweep[f"{kk / B:.2f}"] = {"value": world * B * nsw / dts, "unit": "windows/s", "stage2_windows": kk,
                                       "thr1": state["thr"]}
         state["thr"] = thr_for(args.gate_rate)[0]
@@ -284,14 +289,14 @@ def main():
     if not args.no_fast and args.mode == "f16c8":
         step()
         barrier()
-        ref1 = s1_logits.cpu().numpy().copy()
+        ref1 = s1_logits.copy()
         nsec = max(1, args.steps // 2)
         for key, mode, note in (("x3_mode", "f16x3", "(hi,lo) fp16 pairs, 3 MFMA passes; also meets the 1e-3 logit tolerance"),
                                 ("fast_mode", "f16", "single fp16 MFMA pass; exceeds the 1e-3 logit tolerance, not the headline")):
             m1.set_compute_mode(mode)
             m2.set_compute_mode(mode)
             dtf, _ = timed(nsec, 1)
-            err = float(np.abs(s1_logits.cpu().numpy() - ref1).max())
+            err = float(np.abs(s1_logits - ref1).max())
             out[key] = {"dtype": mode, "value": world * B * nsec / dtf, "unit": "windows/s",
                         "stage1_logit_max_abs_diff_vs_f16c8": err, "note": note}
         m1.set_compute_mode(args.mode)
@@ -301,11 +306,11 @@ def main():
     if rank == 0 and world == 1 and not args.headline_only:
         def stage1_b256(reps=3):
             n256 = min(256, B)
-            ctx.logmel(audio, n_samples, 0, hop, win, n256); ctx.ast_forward(0, None, None, n256, s1_logits)
+            ctx.logmel(audio, n_samples, 0, hop, win, n256); ctx.ast_forward(0, None, None, n256, s1_logits[:n256])
             barrier(); t0 = time.perf_counter()
             for _ in range(reps):
                 ctx.logmel(audio, n_samples, 0, hop, win, n256)
-                ctx.ast_forward(0, None, None, n256, s1_logits)
+                ctx.ast_forward(0, None, None, n256, s1_logits[:n256])
             barrier()
             return n256 * reps / (time.perf_counter() - t0)
         cfg1 = {"workload": "configs[1]: batch=256 windows, stage-1 only (log-mel + AST forward)", "unit": "windows/s"}
@@ -317,7 +322,7 @@ def main():
     # ---- resample line (HBM GB/s of the 48 -> 16 kHz polyphase kernel, reported separately) ----
     if rank == 0 and world == 1 and not args.headline_only:
         n48 = 48000 * 60 * 30                                  # configs[3]'s 30 min at 48 kHz, device-resident fp32
-        a48 = torch.randn(n48, device=dev) * 0.1
+        a48 = torch.randn(n48, device=dev) * 0.1              # (torch only lends the two device buffers of this auxiliary line)
         o16 = torch.empty((n48 + 2) // 3, dtype=torch.float32, device=dev)
         ctx.resample_into(a48, n48, 48000, 16000, o16)
         barrier(); t0 = time.perf_counter()
@@ -353,7 +358,7 @@ def main():
         step()
         barrier()
         out["parity_in_bench"] = {"stage1_logit_max_abs_err_vs_cpu_restatement": float(
-            np.abs(s1_logits.cpu().numpy()[:n_cpu] - r["logits1"]).max()), "windows": n_cpu,
+            np.abs(s1_logits[:n_cpu] - r["logits1"]).max()), "windows": n_cpu,
             "note": "checker = oracle/ast_torch_cpu.py (fp32, numpy-branch log-mel: the extractor branch this build pins; a "
                     "torchaudio-equipped reference install takes the kaldi fp32 branch, see DESIGN.md (c))"}
 
