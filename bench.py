@@ -65,6 +65,13 @@ def main():
     if args.headline_only:
         args.no_fast = args.no_sweep = args.no_cpu = True
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (gloo: "[Gloo] Rank 0 is connected ...",
+    # RCCL: its version banner), so file descriptor 1 is pointed at stderr for the whole run and the line goes to the
+    # saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -363,7 +370,8 @@ def main():
                     "torchaudio-equipped reference install takes the kaldi fp32 branch, see DESIGN.md (c))"}
 
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         if use_rccl:
             ctx.comm_destroy()

@@ -8,36 +8,34 @@ import os
 from typing import Dict, List, Optional, Tuple
 
 
+_CLASS_DIRS = ("Healthy", "Zenker")            # ground truth is the class folder in the recording's path
+_SUFFIX = "_2stage.json"
+# (ground truth, prediction) -> confusion-matrix cell; "Zenker" is the positive class
+_CELL = {("Zenker", "Zenker"): "tp", ("Healthy", "Healthy"): "tn", ("Healthy", "Zenker"): "fp", ("Zenker", "Healthy"): "fn"}
+
+
 def infer_ground_truth(files_used: List[str]) -> str:
-    """:63-72: ground truth from the path of the first file."""
-    if not files_used:
-        return "Unknown"
-    lower = files_used[0].lower()
-    if "/healthy/" in lower:
-        return "Healthy"
-    if "/zenker/" in lower:
-        return "Zenker"
-    return "Unknown"
+    """Class of a patient = the `/Healthy/` or `/Zenker/` folder (any case) in the path of the FIRST recording used;
+    "Unknown" without recordings or without such a folder (utils/aggregate_2stage_results.py:63-72)."""
+    first = files_used[0].lower() if files_used else ""
+    return next((c for c in _CLASS_DIRS if f"/{c.lower()}/" in first), "Unknown")
 
 
 def classify_result(gt: str, ratio: Optional[float], threshold: float) -> Tuple[Optional[str], Dict[str, int]]:
-    """:75-89."""
-    cm = {"tp": 0, "tn": 0, "fp": 0, "fn": 0}
-    if ratio is None or gt == "Unknown":
-        return None, cm
-    pred = "Zenker" if ratio >= threshold else "Healthy"
-    key = {("Healthy", "Healthy"): "tn", ("Healthy", "Zenker"): "fp", ("Zenker", "Zenker"): "tp",
-           ("Zenker", "Healthy"): "fn"}.get((gt, pred))
-    if key:
-        cm[key] = 1
-    return pred, cm
+    """(predicted label, one-hot confusion cell) of one patient: Zenker when the zenker-over-swallow ratio reaches the
+    threshold; no prediction (all cells 0) without a ratio or without ground truth (:75-89)."""
+    cells = dict.fromkeys(("tp", "tn", "fp", "fn"), 0)
+    if ratio is None or gt not in _CLASS_DIRS:
+        return None, cells
+    pred = _CLASS_DIRS[int(ratio >= threshold)]
+    cells[_CELL[(gt, pred)]] = 1
+    return pred, cells
 
 
 def parse_patient_id(filename: str) -> str:
-    base = os.path.basename(filename)
-    if base.endswith("_2stage.json"):
-        return base[: -len("_2stage.json")]
-    return os.path.splitext(base)[0]
+    """`<pid>_2stage.json` -> `<pid>`; any other file name -> its stem."""
+    name = os.path.basename(filename)
+    return name[: -len(_SUFFIX)] if name.endswith(_SUFFIX) else os.path.splitext(name)[0]
 
 
 def aggregate(outputs_dir: str, threshold: float = 0.5):

@@ -14,23 +14,19 @@ from . import pipeline as pl
 
 
 def read_ids(ids_path: str) -> List[str]:
-    """src/run_batch_simple_2stage.py:48-57: "Healthy/224" -> "224"."""
-    patients = []
-    with open(ids_path, "r") as f:
-        for line in f:
-            line = line.strip()
-            if not line:
-                continue
-            patients.append(line.split("/")[-1])
-    return patients
+    """Patient ids of a `test_ids_fold<k>.txt` file: one entry per non-blank line, the id is the last `/`-separated
+    component of the entry (src/run_batch_simple_2stage.py:48-57)."""
+    with open(ids_path) as f:
+        entries = (ln.strip() for ln in f)
+        return [e.rsplit("/", 1)[-1] for e in entries if e]
 
 
 def load_threshold_config(config_path: Optional[str]) -> Optional[dict]:
-    """:60-65."""
-    if not config_path or not os.path.exists(config_path):
-        return None
-    with open(config_path, "r") as f:
-        return json.load(f)
+    """The threshold-config JSON, or None when no path was given or the file does not exist (:60-65)."""
+    if config_path and os.path.isfile(config_path):
+        with open(config_path) as f:
+            return json.load(f)
+    return None
 
 
 def resolve_thresholds(threshold_config: Optional[dict], fold: int) -> Dict[str, float]:

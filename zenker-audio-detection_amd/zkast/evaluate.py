@@ -19,41 +19,41 @@ from .pipeline import SAMPLING_RATE, load_audio
 
 
 def load_split(data_dir: str, fold: int, preferred_split: str) -> Tuple[List, List, str]:
-    """utils/analyze_ROC_PR_stage1.py:116-129 — `<split>_x_fold{k}.npy` / `<split>_y_fold{k}.npy`, val falls back to test."""
-    candidates = [preferred_split, "test"] if preferred_split == "val" else ["test"]
-    for split in candidates:
-        x_path = os.path.join(data_dir, f"{split}_x_fold{fold}.npy")
-        y_path = os.path.join(data_dir, f"{split}_y_fold{fold}.npy")
-        if os.path.exists(x_path) and os.path.exists(y_path):
-            X = np.load(x_path, allow_pickle=True).tolist()
-            y = np.load(y_path).astype(int).tolist()
-            return X, y, split
+    """(snippets, labels, split actually used) of one fold.  Files are `<split>_x_fold<k>.npy` (object array of audio
+    payloads) and `<split>_y_fold<k>.npy`; asking for "val" falls back to "test" when the fold has no validation files,
+    anything else reads "test" (utils/analyze_ROC_PR_stage1.py:116-129)."""
+    for split in ((preferred_split, "test") if preferred_split == "val" else ("test",)):
+        xs, ys = (os.path.join(data_dir, f"{split}_{axis}_fold{fold}.npy") for axis in "xy")
+        if os.path.isfile(xs) and os.path.isfile(ys):
+            return np.load(xs, allow_pickle=True).tolist(), np.load(ys).astype(int).tolist(), split
     raise FileNotFoundError(f"No {preferred_split} or test split found for fold {fold} in {data_dir}.")
 
 
+_DICT_AUDIO_KEYS = ("array", "audio", "values")
+_DICT_RATE_KEYS = ("sampling_rate", "sampling_rate_hz")
+
+
 def to_waveform(entry, device: int = 0) -> np.ndarray:
-    """:132-155 — ndarray | {"array"|"audio"|"values", "sampling_rate"|"sampling_rate_hz"} | path -> mono float32 @ 16 kHz
-    (resampling runs on the GPU, files go through the package's own RIFF reader)."""
-    if isinstance(entry, np.ndarray):
-        return entry.astype(np.float32)
-    if isinstance(entry, dict):
-        arr = next((entry[k] for k in ("array", "audio", "values") if entry.get(k) is not None), None)
-        if arr is None:
-            raise ValueError("Unsupported dict payload for audio sample.")
-        arr = np.asarray(arr, dtype=np.float32)
-        sr = entry.get("sampling_rate") or entry.get("sampling_rate_hz") or SAMPLING_RATE
-        if sr != SAMPLING_RATE:
-            arr = _lib.get_context(device).resample(np.ascontiguousarray(arr), int(sr), SAMPLING_RATE)
-        return arr
+    """One dataset payload -> mono float32 at 16 kHz (:132-155).  Payload kinds: an ndarray (taken as 16 kHz), a dict with
+    the samples under "array" | "audio" | "values" and optionally their rate under "sampling_rate" | "sampling_rate_hz"
+    (resampled on the GPU when it differs), or a path to a WAV file (decoded and resampled on the GPU)."""
     if isinstance(entry, str):
         return load_audio(entry, SAMPLING_RATE, device)
-    raise TypeError(f"Unsupported audio payload type: {type(entry)}")
+    if isinstance(entry, np.ndarray):
+        return entry.astype(np.float32)
+    if not isinstance(entry, dict):
+        raise TypeError(f"Unsupported audio payload type: {type(entry)}")
+    samples = next((entry[k] for k in _DICT_AUDIO_KEYS if entry.get(k) is not None), None)
+    if samples is None:
+        raise ValueError("Unsupported dict payload for audio sample.")
+    wav = np.ascontiguousarray(samples, dtype=np.float32)
+    rate = int(next((entry[k] for k in _DICT_RATE_KEYS if entry.get(k)), SAMPLING_RATE))
+    return wav if rate == SAMPLING_RATE else _lib.get_context(device).resample(wav, rate, SAMPLING_RATE)
 
 
 def batched(iterable: Sequence, batch_size: int):
-    """:158-160"""
-    for i in range(0, len(iterable), batch_size):
-        yield iterable[i : i + batch_size]
+    """Consecutive slices of at most `batch_size` items (:158-160)."""
+    return (iterable[lo:lo + batch_size] for lo in range(0, len(iterable), batch_size))
 
 
 def predict_logits(model: ZkASTForAudioClassification, feature_extractor: ZkASTFeatureExtractor, X: Sequence,

@@ -331,42 +331,51 @@ def build_arg_parser():
     return ap
 
 
-def main(argv=None):
-    args = build_arg_parser().parse_args(argv)
+def _files_of(args) -> List[str]:
+    """The two recordings of the run: given explicitly, or discovered below --long-audio-root for --patient-id."""
     if args.file_a and args.file_b:
-        files = [args.file_a, args.file_b]
-    else:
-        if not (args.patient_id and args.long_audio_root):
-            raise ValueError("Provide either --file-a & --file-b or (--patient-id and --long-audio-root).")
-        files = discover_two_files(args.long_audio_root, args.patient_id, args.pattern)
-    print(f"Using files:\n  A: {files[0]}\n  B: {files[1]}")
-    if args.fold is not None:
-        project_root = os.getcwd()
-        if not args.stage1_model_root:
-            args.stage1_model_root = os.path.join(project_root, "runs", "ast_classifier_stage1", f"fold{args.fold}", "best")
-        if not args.stage2_model_root:
-            args.stage2_model_root = os.path.join(project_root, "runs", "ast_classifier_stage2", f"fold{args.fold}", "best")
-    if not (args.stage1_model_root and args.stage2_model_root):
-        raise ValueError("Model roots must be provided either explicitly or via --fold.")
-    if args.window_sec <= 0 or args.hop_sec <= 0:
+        return [args.file_a, args.file_b]
+    if args.patient_id and args.long_audio_root:
+        return discover_two_files(args.long_audio_root, args.patient_id, args.pattern)
+    raise ValueError("Provide either --file-a & --file-b or (--patient-id and --long-audio-root).")
+
+
+def _model_roots_of(args) -> Tuple[str, str]:
+    """(stage-1 root, stage-2 root): explicit flags win; --fold k fills a missing one with the training scripts' layout
+    `runs/ast_classifier_stage<s>/fold<k>/best` below the working directory."""
+    roots = []
+    for stage, given in ((1, args.stage1_model_root), (2, args.stage2_model_root)):
+        if not given and args.fold is not None:
+            given = os.path.join(os.getcwd(), "runs", f"ast_classifier_stage{stage}", f"fold{args.fold}", "best")
+        if not given:
+            raise ValueError("Model roots must be provided either explicitly or via --fold.")
+        roots.append(given)
+    return roots[0], roots[1]
+
+
+def main(argv=None):
+    """The reference script's command line (same flags, same `<pid>_2stage.json`) on the HIP path."""
+    args = build_arg_parser().parse_args(argv)
+    if min(args.window_sec, args.hop_sec) <= 0:
         raise ValueError("window-sec and hop-sec must be > 0")
+    files = _files_of(args)
+    args.stage1_model_root, args.stage2_model_root = _model_roots_of(args)
+    print("Recordings:", *(f"\n  {tag}: {path}" for tag, path in zip("AB", files)))
     if args.hop_sec > args.window_sec:
-        print("[WARN] hop-sec larger than window-sec; windows will be disjoint with gaps.")
-    fx_s1, model_s1 = load_stage_model(args.stage1_model_root, ["Idle", "Swallow"], 0, args.compute_mode)
-    fx_s2, model_s2 = load_stage_model(args.stage2_model_root, ["Healthy", "Zenker"], 1, args.compute_mode)
+        print("[WARN] hop-sec exceeds window-sec: consecutive windows leave gaps.")
+    stages = [load_stage_model(root, labels, slot, args.compute_mode)
+              for slot, (root, labels) in enumerate(((args.stage1_model_root, ["Idle", "Swallow"]),
+                                                     (args.stage2_model_root, ["Healthy", "Zenker"])))]
+    (fx_s1, model_s1), (fx_s2, model_s2) = stages
     output = run_patient(files, model_s1, fx_s1, model_s2, fx_s2, vars(args))
-    for k, v in output["per_file"].items():
-        print(f"{k}: {v['num_windows']} windows, swallow {v['stage1_swallow_windows']}, zenker {v['stage2_zenker_windows']}")
-    if not args.output_json and args.patient_id:
-        os.makedirs("outputs", exist_ok=True)
-        args.output_json = os.path.join("outputs", f"{args.patient_id}_2stage.json")
-    if args.output_json:
-        out_dir = os.path.dirname(args.output_json)
-        if out_dir:
-            os.makedirs(out_dir, exist_ok=True)
-        with open(args.output_json, "w") as f:
+    for name, rec in output["per_file"].items():
+        print(f"{name}: {rec['num_windows']} windows, swallow {rec['stage1_swallow_windows']}, zenker {rec['stage2_zenker_windows']}")
+    target = args.output_json or (os.path.join("outputs", f"{args.patient_id}_2stage.json") if args.patient_id else None)
+    if target:
+        os.makedirs(os.path.dirname(target) or ".", exist_ok=True)
+        with open(target, "w") as f:
             json.dump(output, f, indent=2)
-        print(f"Saved JSON: {args.output_json}")
+        print(f"Saved JSON: {target}")
     return output
 
 
