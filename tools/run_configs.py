@@ -32,6 +32,14 @@ def main():
     ap.add_argument("--minutes", type=float, default=None, help="recording length (default 30 for config 3, 5 per file for config 4)")
     ap.add_argument("--mode", default="f16c8")
     args = ap.parse_args()
+    # one JSON line on stdout: gloo / RCCL print banners there, so fd 1 goes to stderr and the line to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = 0 if os.environ.get("ZK_BENCH_ONE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
     from zkast import ZkASTConfig, ZkASTFeatureExtractor, ZkASTForAudioClassification, aggregate, batch, lib, pipeline, synth
@@ -100,7 +108,7 @@ def main():
                            "gather_s": round(casc.stats.get("gather_s", 0.0), 6)}).encode()
         per_rank = [json.loads(b.decode()) for b in gather(mine)] if gather else [json.loads(mine.decode())]
         if rank == 0:
-            print(json.dumps({**self_desc, "per_rank": per_rank, "config": "configs[3]: %.0f-min 48 kHz PCM16 recording, 1 s / 0.5 s-hop windows sharded over %d GPU(s)"
+            emit(({**self_desc, "per_rank": per_rank, "config": "configs[3]: %.0f-min 48 kHz PCM16 recording, 1 s / 0.5 s-hop windows sharded over %d GPU(s)"
                               % (minutes, world), "n_gpus": world, "windows": int(casc.n_windows), "gated_windows": int(len(idx)),
                               "seconds_end_to_end": dt, "windows_per_s": casc.n_windows / dt,
                               "file_bytes": len(pcm), "bytes_uploaded_by_rank0": int(casc.h2d_samples),
@@ -132,7 +140,7 @@ def main():
         if rank == 0:
             summary, rows = aggregate.aggregate(os.path.join(tmp, "out"), 0.5)
             nwin = sum(v["total_windows"] for v in summ.values())
-            print(json.dumps({**self_desc, "config": "configs[4]: %d synthetic patients x 2 files x %.0f min @16 kHz, patient-sharded over %d GPU(s), "
+            emit(({**self_desc, "config": "configs[4]: %d synthetic patients x 2 files x %.0f min @16 kHz, patient-sharded over %d GPU(s), "
                               "in-process batch driver + patient-level aggregation" % (args.patients, minutes, world),
                               "n_gpus": world, "patients_ok": sum(v == "ok" for v in st.values()), "windows": int(nwin),
                               "seconds_end_to_end": dt, "windows_per_s": nwin / dt,
