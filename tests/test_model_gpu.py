@@ -306,6 +306,35 @@ def test_feature_cache_roundtrip_and_probs_from_features(tmp_path):
     assert cache.forward_probs_from_features(model, f2[:0], 4).shape == (0, 0)
 
 
+def test_features_set_contract():
+    """zk_features_set (C ABI): what it accepts, what it refuses, and that a forward on the slot afterwards equals the
+    forward on the log-mel the library computed itself."""
+    import torch
+    from zkast import lib, synth
+    model, _ = _model(12, "init", 0)
+    ctx = lib.get_context(0)
+    wins = synth.synth_windows(5, 3)
+    ctx.logmel(np.ascontiguousarray(wins.reshape(-1)), wins.size, 0, 16000, 16000, 3)
+    own = ctx.features_get()
+    ref = model.forward_from_slot(3)
+    ctx.features_set(np.zeros((1, 98, 128), np.float32))             # overwrite the slot ...
+    assert ctx.features_shape() == (1, 98)
+    ctx.features_set(own)                                            # ... and put the store back (host source)
+    assert ctx.features_shape() == (3, 98) and np.array_equal(ctx.features_get(), own)
+    assert np.array_equal(model.forward_from_slot(3), ref)
+    ctx.features_set(torch.from_numpy(own[:2]).cuda())               # device source
+    assert np.array_equal(model.forward_from_slot(2), ref[:2])
+    ctx.features_set(own[:, :40])                                    # any frame count 1..1024 (shorter windows)
+    assert ctx.features_shape() == (3, 40)
+    with pytest.raises(ValueError):
+        ctx.features_set(np.zeros((2, 98, 64), np.float32))          # 128 mel bins only
+    with pytest.raises(lib.ZkError):
+        ctx.features_set(np.zeros((2, 1025, 128), np.float32))       # more frames than max_length
+    ctx.features_set(np.zeros((0, 98, 128), np.float32))             # empty slot: a forward on it is refused
+    with pytest.raises(lib.ZkError):
+        model.forward_from_slot(1)
+
+
 def test_compact_cache_feeds_both_stages_by_affine_renormalisation(tmp_path):
     """ONE compact (N,98,128) store serves both stages although their extractors differ in mean/std — the
     store goes to the device slot once (zk_features_set) and each stage normalises it with its own statistics.  The
