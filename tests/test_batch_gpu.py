@@ -133,3 +133,46 @@ def test_snippet_level_evaluation_loop(tmp_path):
     w16 = orc.resample_sinc_hann(w48, 48000, 16000)
     r48 = orc.softmax(orc.ast_forward(orc.extract_features([w16], mean, std), W))[0, 1]
     assert abs(float(s48[0]) - float(r48)) <= 1e-3
+
+
+def test_cli_with_feature_cache_equals_the_uncached_run(tmp_path):
+    """The cached variant's options on the command line (--feature-cache-dir / --refresh-cache / --disable-cache,
+    src/test_long_audio_windows_2stage_cache.py:361-375): same JSON as the uncached run; the second run is served by the
+    compact stores; with only the reference-format `.pt` twins left in the directory (what the reference script writes)
+    the run imports those and still agrees."""
+    import glob
+    from zkast import pipeline, synth
+    cas = np.load(os.path.join(os.path.dirname(__file__), "golden", "cascade.npz"))
+    sd1 = synth.make_ast_weights(int(cas["s1_seed"]), "wide")
+    sd1["classifier.dense.bias"][1] += np.float32(cas["s1_bias_shift"])
+    sd2 = synth.make_ast_weights(int(cas["s2_seed"]), "wide")
+    sd2["classifier.dense.bias"][1] += np.float32(cas["s2_bias_shift"])
+    m1, m2 = str(tmp_path / "s1"), str(tmp_path / "s2")
+    _save_model_dir(m1, sd1, float(cas["s1_mean"]), float(cas["s1_std"]), ["Idle", "Swallow"])
+    _save_model_dir(m2, sd2, float(cas["s2_mean"]), float(cas["s2_std"]), ["Healthy", "Zenker"])
+    wavs = []
+    for k in range(2):
+        path = str(tmp_path / f"rec{k}.wav")
+        pipeline.write_wav_pcm16(path, synth.synth_recording(70 + k, 16000 * 4 + 321), 16000)
+        wavs.append(path)
+    base = ["--stage1-model-root", m1, "--stage2-model-root", m2, "--file-a", wavs[0], "--file-b", wavs[1],
+            "--stage2-threshold", "0.45"]
+    plain = pipeline.main(base + ["--output-json", str(tmp_path / "plain.json")])
+    cdir = str(tmp_path / "cache")
+    first = pipeline.main(base + ["--feature-cache-dir", cdir, "--output-json", str(tmp_path / "c1.json")])
+    stores = sorted(glob.glob(os.path.join(cdir, "*.zkc.npz")))
+    bundles = sorted(glob.glob(os.path.join(cdir, "*.pt")))
+    assert len(stores) == 2 and len(bundles) == 2
+    stamp = [os.path.getmtime(p) for p in stores]
+    second = pipeline.main(base + ["--feature-cache-dir", cdir, "--output-json", str(tmp_path / "c2.json")])
+    assert [os.path.getmtime(p) for p in stores] == stamp                      # served from the cache, nothing rewritten
+    for p in stores:
+        os.remove(p)                                                            # leave only what the reference writes
+    imported = pipeline.main(base + ["--feature-cache-dir", cdir, "--output-json", str(tmp_path / "c3.json")])
+    off = pipeline.main(base + ["--feature-cache-dir", cdir, "--disable-cache", "--output-json", str(tmp_path / "c4.json")])
+    for run in (first, second, off):
+        assert run["per_file"] == plain["per_file"] and run["aggregate"] == plain["aggregate"]
+    for k in plain["per_file"]:                # imported bundles: log-mel differs by <= 1 ulp, the counts must still agree
+        a, b = plain["per_file"][k], imported["per_file"][k]
+        assert {x: a[x] for x in a if "windows" in x} == {x: b[x] for x in b if "windows" in x}
+        assert np.abs(np.array(a["stage1_mean_probs"]) - np.array(b["stage1_mean_probs"])).max() <= 1e-5

@@ -8,12 +8,12 @@ the library or a gfx950 device is missing.
 from .feature_extraction import ZkASTFeatureExtractor  # noqa: F401
 from .modeling import ZkASTConfig, ZkASTForAudioClassification  # noqa: F401
 from .pipeline import (SAMPLING_RATE, classify_recording, forward_probs,  # noqa: F401
-                       forward_probs_recording, load_audio, load_audio_to_device, load_stage_model, run_patient,
+                       classify_features, forward_probs_recording, load_audio, load_audio_to_device, load_stage_model, run_patient,
                        summarize_stage_outputs, window_audio, window_geometry)
 
 __all__ = [
     "ZkASTFeatureExtractor", "ZkASTConfig", "ZkASTForAudioClassification", "SAMPLING_RATE",
-    "classify_recording", "forward_probs", "forward_probs_recording", "load_audio", "load_audio_to_device",
+    "classify_recording", "classify_features", "forward_probs", "forward_probs_recording", "load_audio", "load_audio_to_device",
     "load_stage_model",
     "run_patient", "summarize_stage_outputs", "window_audio", "window_geometry",
 ]

@@ -239,6 +239,35 @@ def classify_recording(audio: np.ndarray, model_s1, fx_s1, model_s2, fx_s2, wind
     s1_logits, swallow_indices, s2_logits = ctx.two_stage(
         None if audio is None else np.ascontiguousarray(audio, dtype=np.float32), n_samples, 0, hop, win, n,
         np.float32(stage1_threshold), stage1_forward_min_prob)
+    return _decide(ctx, s1_logits, swallow_indices, s2_logits, stage1_threshold, stage2_threshold, stage2_argmax,
+                   stage1_label_order, stage2_label_order)
+
+
+def classify_features(store, model_s1, fx_s1, model_s2, fx_s2, stage1_threshold: float = 0.5,
+                      stage2_threshold: float = 0.5, stage1_forward_min_prob: Optional[float] = None,
+                      stage2_argmax: bool = False, stage1_label_order=("Idle", "Swallow"),
+                      stage2_label_order=("Healthy", "Zenker")):
+    """classify_recording for a recording whose log-mel comes out of the feature cache (`zkast.cache.CompactFeatures`):
+    the store goes into the device slot once, stage 1 runs on it, the gate on the device, stage 2 on the gated windows of
+    the SAME slot re-normalised with stage 2's mean / std.  Same return value as classify_recording."""
+    ctx = model_s1._ctx
+    model_s1.bind_feature_extractor(fx_s1)
+    model_s2.bind_feature_extractor(fx_s2)
+    n = len(store)
+    if n == 0:
+        raise RuntimeError("the cached feature store holds no windows")
+    store.to_device(ctx)
+    s1_logits = model_s1.forward_from_slot(n)
+    _probs, swallow_indices = ctx.gate(s1_logits, np.float32(stage1_threshold), stage1_forward_min_prob)
+    s2_logits = (model_s2.forward_from_slot(len(swallow_indices), swallow_indices) if len(swallow_indices)
+                 else np.zeros((0, 2), np.float32))
+    return _decide(ctx, s1_logits, swallow_indices, s2_logits, stage1_threshold, stage2_threshold, stage2_argmax,
+                   stage1_label_order, stage2_label_order)
+
+
+def _decide(ctx, s1_logits, swallow_indices, s2_logits, stage1_threshold, stage2_threshold, stage2_argmax,
+            stage1_label_order, stage2_label_order):
+    """Logits of the cascade -> (summary dict, s1_probs, s1_preds, stage2_aligned_classes, stage2_results) (:307-348)."""
     s1_probs = ctx.softmax(s1_logits)
     if s1_probs.ndim != 2 or s1_probs.shape[1] != 2:
         raise RuntimeError("Stage1 output shape unexpected; expected (N,2)")
@@ -256,6 +285,22 @@ def classify_recording(audio: np.ndarray, model_s1, fx_s1, model_s2, fx_s2, wind
     summary = summarize_stage_outputs(s1_probs, stage2_results, list(stage1_label_order), list(stage2_label_order),
                                       stage2_threshold, stage2_argmax)
     return summary, s1_probs, s1_preds, stage2_aligned_classes, stage2_results
+
+
+def _cached_features(path: str, ctx, fx, window_sec: float, hop_sec: float, cache_dir: str, refresh: bool, log=print):
+    """Compact log-mel of the recording in the context's audio slot, through `zkast.cache.FeatureCache`: a store (or a
+    reference `.pt` bundle) of this file / window grid / extractor is used when present, otherwise the device computes
+    the log-mel and the entry is written (compact store + reference-format twin)."""
+    from . import cache as _cache
+    n, win, hop = window_geometry(ctx.audio_len(), window_sec, hop_sec)
+    fc = _cache.FeatureCache(cache_dir, log=log)
+    key = _cache.EntryKey.of(path, window_sec, hop_sec, SAMPLING_RATE, _cache.get_fx_fingerprint(fx))
+    store = None if refresh else fc.lookup(key, n, fx)
+    if store is None:
+        ctx.logmel(None, 0, 0, hop, win, n)
+        store = _cache.CompactFeatures.from_device(ctx, extractor="zk_logmel")
+        fc.store(key, store, fx)
+    return store
 
 
 def aggregate_files(per_file: Dict[str, Dict[str, Any]], files: List[str]) -> Dict[str, Any]:
@@ -281,16 +326,22 @@ def run_patient(files: List[str], model_s1, fx_s1, model_s2, fx_s2, args_like: D
                 audios: Optional[List[np.ndarray]] = None) -> Dict[str, Any]:
     """The `output` dict main() writes as <pid>_2stage.json (:384-396), for two files (or in-memory recordings)."""
     per_file = {}
+    window_sec, hop_sec = args_like.get("window_sec", 1.0), args_like.get("hop_sec", 0.5)
+    decide = (args_like.get("stage1_threshold", 0.5), args_like.get("stage2_threshold", 0.5),
+              args_like.get("stage1_forward_min_prob"), args_like.get("stage2_argmax", False))
+    cache_dir = None if args_like.get("disable_cache") else args_like.get("feature_cache_dir")
     for idx, path in enumerate(files):
         if audios is not None:
             audio = audios[idx]
         else:      # file -> device once; decode, resample, log-mel and both forwards read it there
             load_audio_to_device(path, device=getattr(model_s1, "_device", 0))
             audio = None
-        summary, *_ = classify_recording(
-            audio, model_s1, fx_s1, model_s2, fx_s2, args_like.get("window_sec", 1.0), args_like.get("hop_sec", 0.5),
-            args_like.get("stage1_threshold", 0.5), args_like.get("stage2_threshold", 0.5),
-            args_like.get("stage1_forward_min_prob"), args_like.get("stage2_argmax", False))
+        if cache_dir and audios is None:      # the cached variant's options (..._cache.py:361-375): features via the cache
+            store = _cached_features(path, model_s1._ctx, fx_s1, window_sec, hop_sec, cache_dir,
+                                     bool(args_like.get("refresh_cache")), args_like.get("log", print))
+            summary, *_ = classify_features(store, model_s1, fx_s1, model_s2, fx_s2, *decide)
+        else:
+            summary, *_ = classify_recording(audio, model_s1, fx_s1, model_s2, fx_s2, window_sec, hop_sec, *decide)
         per_file[f"file_{idx}"] = {"path": path, **summary}
     return {
         "config": {
@@ -328,6 +379,12 @@ def build_arg_parser():
     ap.add_argument("--output-json")
     ap.add_argument("--show-first-n", type=int, default=5)
     ap.add_argument("--compute-mode", default="f16c8", choices=["f16", "f16c8", "f16x3"])
+    # the cached variant's cache options (..._cache.py:361-375); here the cache is OFF unless a directory is given — the
+    # device log-mel costs 0.5 ms per 1 024 windows, the cache only matters for exchanging features with the reference
+    ap.add_argument("--feature-cache-dir", default=None,
+                    help="Directory of cached features (this build's compact stores and the reference's .pt bundles).")
+    ap.add_argument("--disable-cache", action="store_true", help="Ignore --feature-cache-dir.")
+    ap.add_argument("--refresh-cache", action="store_true", help="Recompute and overwrite existing cache entries.")
     return ap
 
 
