@@ -524,6 +524,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           v[j] = oacc[mb][4 * rg + j] * inv;
+          zk_pin(v[j]);
           hi[j] = (half_t)v[j];
         }
         *(h4_t*)(stg + (lane & 31) * O_STR + d * 2) = hi;

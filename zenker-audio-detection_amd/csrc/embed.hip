@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ s
     } else {
       v = src[((size_t)w * ZK_MAXLEN + time) * ZK_NMEL + mel];
     }
+    zk_pin(v);
     hi[j] = (half_t)v;
     vv[j] = v;
   }

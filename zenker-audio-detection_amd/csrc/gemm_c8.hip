@@ -330,6 +330,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
               v[0] = g01[0]; v[1] = g01[1]; v[2] = g23[0]; v[3] = g23[1];
             }
             h4_t hi;
+            if constexpr (LOFMT >= 0) zk_pin(v);      // hi and lo must come from the same rounded value
 #pragma unroll
             for (int e = 0; e < 4; ++e) hi[e] = (half_t)v[e];
             if constexpr (LOFMT >= 0) {

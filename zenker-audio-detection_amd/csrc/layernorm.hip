@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       y[j] = y3[i][j] * rs;
+      zk_pin(y[j]);
       hi[j] = (half_t)y[j];
     }
     *(h4_t*)(o_hi + (size_t)row * ZK_HIDDEN + c) = hi;

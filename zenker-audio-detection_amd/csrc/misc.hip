@@ -13,7 +13,8 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
     h4_t h, l;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float x = v[j] * scale;
+      float x = v[j] * scale;
+      zk_pin(x);
       h[j] = (half_t)x;
       l[j] = (half_t)(x - (float)h[j]);
     }
@@ -63,10 +64,10 @@ __global__ __launch_bounds__(256) void split_rows_c8_kernel(const float* __restr
   if (lane == 0) rowexp[row] = sx;
   for (int c = lane * 4; c < K; c += 256) {
     const f4_t v = *(const f4_t*)(xr + c);
-    const float y[4] = {v[0] * rs, v[1] * rs, v[2] * rs, v[3] * rs};
+    float y[4] = {v[0] * rs, v[1] * rs, v[2] * rs, v[3] * rs};
     h4_t h;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = (half_t)y[j];
+    for (int j = 0; j < 4; ++j) { zk_pin(y[j]); h[j] = (half_t)y[j]; }
     *(h4_t*)(hi + (size_t)row * K + c) = h;
     *(h4_t*)(c8 + (size_t)row * K + c) = zk_lo4(y, h, ZK_LO_C8);
   }

@@ -62,17 +62,32 @@ __device__ __forceinline__ int zk_row_exponent(float amax) {
   int s = (f <= 0.875f) ? e - 8 : e - 7; // 224 = 0.875·2^8
   return s < -40 ? -40 : (s > 40 ? 40 : s);
 }
-__device__ __forceinline__ float zk_clamp_fp8(float x) { return __builtin_fminf(__builtin_fmaxf(x, -448.f), 448.f); }
-// two consecutive elements (value v, its fp16 rounding h) -> one dword of two (lo8, x8) byte pairs (OCP e4m3, RNE)
-__device__ __forceinline__ unsigned zk_c8_pack2(float v0, float h0, float v1, float h1) {
-  int p = __builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8((v0 - h0) * 2048.f), zk_clamp_fp8(v0), 0, false);
-  p = __builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8((v1 - h1) * 2048.f), zk_clamp_fp8(v1), p, true);
+// clamp to e4m3's finite range: v_cvt_pk_fp8_f32 does NOT saturate (probed on gfx950: 448 < |x| <= 464 rounds to 448, beyond
+// that the byte is NaN).  v_med3_f32 directly: the fminf(fmaxf()) form costs a second instruction (hipcc quiets a possible
+// signalling NaN with v_max x,x first).
+__device__ __forceinline__ float zk_clamp_fp8(float x) { return __builtin_amdgcn_fmed3f(x, -448.f, 448.f); }
+// two consecutive elements (values v0, v1; h01 = their fp16 roundings, packed) -> one dword of two (lo8, x8) byte pairs
+// (OCP e4m3, RNE).  v - fp16(v) comes from ONE v_fma_mix_f32 that reads the fp16 half in place (the difference is exact in
+// fp32 either way), and the first conversion writes into whatever `old` holds — its upper half is overwritten by the second.
+__device__ __forceinline__ unsigned zk_c8_pack2(float v0, float v1, h2_t h01) {
+  float l0, l1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h01), "v"(v0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h01), "v"(v1));
+  int p = __builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8(l0 * 2048.f), zk_clamp_fp8(v0), __builtin_bit_cast(int, v0), false);
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(zk_clamp_fp8(l1 * 2048.f), zk_clamp_fp8(v1), p, true);
   return (unsigned)p;
 }
+// Pin a computed fp32 value before its (hi, lo) planes are derived from it.  hipcc contracts across statements
+// (-ffp-contract=fast): (half_t)(a * b) may become ONE v_fma_mixlo_f16 — a single rounding of the exact product — in one
+// use and fp16(fp32(a * b)) in another, and a lo entry computed against a different hi than the one that was stored is off
+// by a whole fp16 ulp (seen in round 3: attention's fp16 lo plane, 1.3e-4 -> 4.5e-4 of max|ref| after an unrelated edit
+// of this header).  The empty asm makes the value opaque: every later use sees the same rounded fp32 number.
+__device__ __forceinline__ void zk_pin(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void zk_pin(f4_t& x) { asm volatile("" : "+v"(x)); }
 // lo plane entries of 4 consecutive elements in either format
 __device__ __forceinline__ h4_t zk_lo4(const float* v, h4_t hi, int fmt) {
   if (fmt == ZK_LO_C8) {
-    unsigned d[2] = {zk_c8_pack2(v[0], (float)hi[0], v[1], (float)hi[1]), zk_c8_pack2(v[2], (float)hi[2], v[3], (float)hi[3])};
+    unsigned d[2] = {zk_c8_pack2(v[0], v[1], h2_t{hi[0], hi[1]}), zk_c8_pack2(v[2], v[3], h2_t{hi[2], hi[3]})};
     return __builtin_bit_cast(h4_t, d);
   }
   h4_t lo;
