@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-timeout -k 10 900 bash tools/profile_round.sh r03 > gpurun_out/r3x_profile.log 2>&1
-timeout -k 10 900 python bench.py --steps 20 --warmup 1 > gpurun_out/r3x_bench20.json 2> gpurun_out/r3x_bench20.err
-timeout -k 10 300 python tools/run_configs.py --config 3 > gpurun_out/r3x_cfg3.json 2> gpurun_out/r3x_cfg3.err
-timeout -k 10 300 python tools/run_configs.py --config 4 > gpurun_out/r3x_cfg4.json 2> gpurun_out/r3x_cfg4.err
+timeout -k 10 900 python -m pytest tests -m gpu -q -s 2>&1 | grep -h "max-abs logit err\|passed\|failed\|FAILED" > gpurun_out/r3z_tests.log
+timeout -k 10 500 python tools/gemm_ab_multi.py 512 5 old,base > gpurun_out/r3z_gemm_ab.log 2>&1
+timeout -k 10 300 python bench.py --headline-only --steps 5 > gpurun_out/r3z_bench_new.json 2> gpurun_out/r3z_bench_new.err
+ZKAST_LIB=$PWD/zenker-audio-detection_amd/zkast/libzkast_old.so timeout -k 10 300 python bench.py --headline-only --steps 5 > gpurun_out/r3z_bench_old.json 2> gpurun_out/r3z_bench_old.err
