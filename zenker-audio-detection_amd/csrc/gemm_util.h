@@ -27,21 +27,29 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // two elements at a time: the Horner chain as v_pk_fma_f32 (hipcc turns the scalar form above into one v_fmaak_f32 per
 // coefficient and element, twice the issue slots)
 typedef float gelu_f2_t __attribute__((ext_vector_type(2)));
-struct gelu_coef_t { float c[9]; };
+#ifndef ZK_GELU_DEG
+#define ZK_GELU_DEG 8
+#endif
+struct gelu_coef_t { float c[ZK_GELU_DEG + 1]; };
 // the coefficients as opaque scalar registers, fetched once per epilogue (an empty asm hides the literals: folded into the
 // instructions they would turn every packed fma back into two v_fmaak_f32)
 __device__ __forceinline__ gelu_coef_t gelu_coefficients() {
+#if ZK_GELU_DEG == 6      // probe: degree-6 fit (|error| 1.3e-7, relative error of the negative tail 5e-4 up to |x| = 5)
+  gelu_coef_t k = {{9.999952316e-01f, 1.151190996e+00f, 4.587764442e-01f, 5.343326181e-02f, -8.108191192e-03f,
+                    7.806957001e-04f, -3.466758062e-05f}};
+#else
   gelu_coef_t k = {{9.999988675e-01f, 1.151123285e+00f, 4.591154456e-01f, 5.271420255e-02f, -7.333386224e-03f,
                     3.233428288e-04f, 1.144626513e-04f, -2.508334364e-05f, 1.690407657e-06f}};
+#endif
 #pragma unroll
-  for (int i = 0; i < 9; ++i) asm volatile("" : "+s"(k.c[i]));
+  for (int i = 0; i <= ZK_GELU_DEG; ++i) asm volatile("" : "+s"(k.c[i]));
   return k;
 }
 __device__ __forceinline__ gelu_f2_t gelu_erf2(gelu_f2_t x, const gelu_coef_t& k) {
   const gelu_f2_t u = {fminf(fabsf(x[0]), 8.0f), fminf(fabsf(x[1]), 8.0f)};
-  gelu_f2_t p = {k.c[8], k.c[8]};
+  gelu_f2_t p = {k.c[ZK_GELU_DEG], k.c[ZK_GELU_DEG]};
 #pragma unroll
-  for (int i = 7; i >= 0; --i) p = __builtin_elementwise_fma(p, u, gelu_f2_t{k.c[i], k.c[i]});
+  for (int i = ZK_GELU_DEG - 1; i >= 0; --i) p = __builtin_elementwise_fma(p, u, gelu_f2_t{k.c[i], k.c[i]});
   const gelu_f2_t s2 = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
   const gelu_f2_t r = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
   return r - u * s2;
