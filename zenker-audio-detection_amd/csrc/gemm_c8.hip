@@ -29,7 +29,7 @@
 
 namespace {
 
-// the 8 LDS-DMA pieces a wave issues per step: 2 in the deferred tile right behind the step barrier (chunk -1), 2 in
+// symmetric form (ZK_C8_ROLES=0): the 8 LDS-DMA pieces a wave issues per step: 2 in the deferred tile right behind the step barrier (chunk -1), 2 in
 // each of chunks 0..2 (measured best of four placements; a piece costs ~100 issue cycles among MFMAs)
 constexpr int c8_cnt(int c) {
   constexpr int T[8] = {2, 2, 2, 2, 0, 0, 0, 0};
@@ -42,6 +42,36 @@ constexpr int c8_piece(int c, int g, int G) {
   for (int q = 0; q < n; ++q) if (q * G / n == g) return c8_base(c) + q;
   return -1;
 }
+
+// Roles (ZK_C8_ROLES = piece table, 0 = the symmetric round-1/2 form above; ZK_C8_RLOAD = which half loads): the two waves
+// of a SIMD take different roles — the LOADER wave issues all 16 LDS-DMA pieces of its SIMD per step, its partner issues
+// none, so one MFMA stream per SIMD never stalls at a vector-memory issue.  Measured (profiles/r03_gemm_roles_ab.txt,
+// bit-identical outputs): loaders = the OLDER waves 0-3 +1.5…2.9 % on all four GEMM shapes, loaders = waves 4-7 −4…−10 %
+// (the younger wave loses the matrix-pipe arbitration anyway; stalled at pieces on top of that it becomes the straggler
+// of every step).  Table = pieces per chunk (-1 .. 6); front-loaded 4-4-4-4 is the production one.
+#ifndef ZK_C8_ROLES
+#define ZK_C8_ROLES 1
+#endif
+#ifndef ZK_C8_RLOAD
+#define ZK_C8_RLOAD 0
+#endif
+#if ZK_C8_ROLES
+constexpr int c8r_cnt(int c) {
+#if ZK_C8_ROLES == 1
+  constexpr int T[8] = {4, 4, 4, 4, 0, 0, 0, 0};
+#elif ZK_C8_ROLES == 2
+  constexpr int T[8] = {2, 2, 2, 2, 2, 2, 2, 2};
+#elif ZK_C8_ROLES == 3
+  constexpr int T[8] = {16, 0, 0, 0, 0, 0, 0, 0};
+#elif ZK_C8_ROLES == 4
+  constexpr int T[8] = {8, 8, 0, 0, 0, 0, 0, 0};
+#else
+  constexpr int T[8] = {4, 3, 3, 2, 2, 2, 0, 0};
+#endif
+  return T[c + 1];
+}
+constexpr int c8r_base(int c) { int b = 0; for (int q = -1; q < c; ++q) b += c8r_cnt(q); return b; }
+#endif
 
 // compile-time loop: f(integral_constant<int, I>) for I in [0, N) — the loop index ends up in "n" asm operands
 template <class F, int... I>
@@ -64,12 +94,16 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   constexpr int TM = BM / WM, TN = BN / WN;       // 128 x 64 per wave
   constexpr int RM = TM / 16, RN = TN / 16;       // 8 X tiles, 4 W tiles
   constexpr int XBYTES = BM * ROWB, WBYTES = BN * ROWB, STAGE = XBYTES + WBYTES;
-  constexpr int XI = BM / RPI / 8, WI = BN / RPI / 8, LPT = XI + WI;   // 1-KiB LDS-DMA pieces per wave and step
+  constexpr int XI = BM / RPI / 8, WI = BN / RPI / 8;
+  [[maybe_unused]] constexpr int LPT = XI + WI;   // 1-KiB LDS-DMA pieces per wave and step
   constexpr int BIAS_OFF = 2 * STAGE;
   constexpr int SCR_OFF = BIAS_OFF + 2 * 8 * 256;
   constexpr int SCR_STR = 144, SCR_WAVE = 16 * SCR_STR;
   constexpr int RSC_OFF = SCR_OFF + 8 * SCR_WAVE;      // per wave: 128 row scales (fp32) of its X rows, epilogue only
   constexpr int TILE_B = 16 * ROWB;               // 2048 B between consecutive 16-row tiles
+#ifdef ZK_C8_PF2
+  constexpr int PF_OFF = RSC_OFF + 8 * 512;       // probe: 256 B per wave, landing strip of the L2-prefetch dwords (never read)
+#endif
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -121,7 +155,11 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   // of the last row block are read as they lie — the planes hold whole 256-row tiles, zk_gemm_args — and never stored.)
   unsigned poff;
   {
+#if ZK_C8_ROLES
+    const int row = (wave & 3) * RPI + srow;      // loader lw = wave & 3 covers 8-row units lw and lw + 4 of every 64 rows
+#else
     const int row = wave * RPI + srow;
+#endif
     const int c = schunk ^ ((row >> 1) & (CPR - 1));
     poff = (unsigned)row * (unsigned)(a.K * 2) + (unsigned)(c * 16);
   }
@@ -160,6 +198,60 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
                                        4, 0, 0);
     }
   };
+#if ZK_C8_ROLES
+  // loader-role piece p of 16: X pieces 0..7, W pieces 8..15; piece (q, h) = (p >> 1 & 3, p & 1) covers the 8-row unit
+  // q·8 + lw + 4h of its operand (rows q·64 + h·32 + lw·8 + srow: the swizzle term (row >> 1) & 7 depends on lw, srow only)
+  auto issue_piece_r = [&](auto kind_c, int p) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    char* base = smem + KIND * STAGE;
+    const half_t* xpl = KIND ? a.x_lo : a.x_hi;
+    const half_t* wpl = KIND ? a.w_lo : a.w_hi;
+    const int k0 = l_k * BK;
+    const int q = (p >> 1) & 3, h = p & 1, unit = q * 8 + (wave & 3) + 4 * h;
+    const bool isw = p >= 8;
+    const half_t* pl = isw ? wpl : xpl;
+    const int r0 = (isw ? l_n0 : l_m0) + q * 64 + h * 32;
+    const char* gb = uniform_ptr((const char*)(pl + (size_t)r0 * a.K + k0));
+    asm volatile("" : "+v"(poff));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + poff),
+                                     (__attribute__((address_space(3))) void*)(base + (isw ? XBYTES : 0) + unit * 1024), 16, 0, 0);
+    if (KIND == 0 && p == 0) {
+      unsigned l4;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 2, %0" : "=v"(l4));
+      const char* src = uniform_ptr((const char*)(a.bias + l_n0 + wn * TN)) + l4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + BIAS_OFF +
+                                                                                 ((l_ord & 1) * 8 + (wave & 3)) * 256),
+                                       4, 0, 0);
+    }
+  };
+#endif
+#ifdef ZK_C8_PF2
+  // probe -DZK_C8_PF2=<d>: second form of the cooperative L2 prefetch of the X panel (first form: tools/archive/
+  // gemm_c8_l2_prefetch_variant.hip.txt).  The workgroup of column tile tn touches rows [tn·pf_rows, (tn+1)·pf_rows) of the
+  // X lines of the ring step d steps past the load cursor.  Every wave touches its eighth of them (one instruction, most lanes on
+  // the same line).  The touch is the LAST vector-memory instruction of the step and the step closes on vmcnt(1), so the HBM round trip of the touch stays in flight across the barrier instead of ending the step.
+  const int pf_rows = (BM + tiles_n - 1) / tiles_n;
+  const int pf_pw = (pf_rows + 7) >> 3;          // rows per wave: every wave touches (no wave-dependent branch in the step)
+  auto pf_issue = [&](auto ck_c) __attribute__((always_inline)) {
+    constexpr int CK = decltype(ck_c)::value;      // kind of the step at the load cursor
+    constexpr int TK = (CK + ZK_C8_PF2) & 1, DK = (CK + ZK_C8_PF2) >> 1;
+    // (the first steps of the NEXT tile are not prefetched: tracking its row block costs k-loop registers the kernel does
+    // not have — 21 spilled VGPRs when tried; past the tile the touch re-reads lines of this tile's last step)
+    const int k = min(l_k + DK, nk - 1), m0 = l_m0, tn = l_n0 / BN;
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    int rmax = min(tn * pf_rows + pf_rows, BM) - 1;
+    rmax = min(rmax, a.M - 1 - m0);
+    const int r0 = tn * pf_rows + wave * pf_pw;
+    const int r = min(r0 + min(ln, pf_pw - 1), rmax);
+    const half_t* xpl = TK ? a.x_lo : a.x_hi;
+    const char* gb = uniform_ptr((const char*)(xpl + (size_t)m0 * a.K + k * BK));
+    const char* src = gb + (unsigned)r * (unsigned)(a.K * 2);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smem + PF_OFF + wave * 256), 4, 0, 0);
+  };
+#endif
   auto advance_load = [&](auto kind_c) __attribute__((always_inline)) {
     constexpr int KIND = decltype(kind_c)::value;
     ++l_step;
@@ -229,7 +321,11 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   auto epilogue = [&]() __attribute__((always_inline)) {
     const int pt = phys(c_tile), tm = pt / tiles_n, tn = pt - tm * tiles_n;
     const int m0 = tm * BM + wm * TM, n0 = tn * BN + wn * TN;
+#if ZK_C8_ROLES
+    const char* bslot = smem + BIAS_OFF + ((c_ord & 1) * 8 + (wave & 3)) * 256;
+#else
     const char* bslot = smem + BIAS_OFF + ((c_ord & 1) * 8 + wave) * 256;
+#endif
     f4_t b4[RN];
 #pragma unroll
     for (int i = 0; i < RN; ++i) b4[i] = *(const f4_t*)(bslot + (i * 16 + 4 * fq) * 4);
@@ -382,8 +478,19 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   using H1 = K1;
 
   // prologue: step 0 (main, slot 0) lands before anything is read
+#if ZK_C8_ROLES
+  const bool is_loader = ZK_C8_RLOAD ? wave >= 4 : wave < 4;
+#ifdef ZK_C8_RPRIO      // probe: static priority for one role (1 = the piece-free waves, 2 = the loaders)
+  if ((ZK_C8_RPRIO == 2) == is_loader) __builtin_amdgcn_s_setprio(1);
+#endif
+  if (is_loader) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) issue_piece_r(K0{}, p);
+  }
+#else
 #pragma unroll
   for (int pc = 0; pc < LPT; ++pc) issue_piece(K0{}, pc);
+#endif
   advance_load(K0{});
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
@@ -392,15 +499,36 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   bool epi_pending = false;
 
   // one ring step of kind KIND (its slot), prefetching the following step (kind KIND^1) into the other slot
-  auto step = [&](auto kind_c) __attribute__((always_inline)) {
+  // ROLE: 0 = every wave issues its 8 pieces (production), 1 = loader role (16 pieces), 2 = no pieces
+  auto step = [&](auto kind_c, auto role_c) __attribute__((always_inline)) {
     constexpr int KIND = decltype(kind_c)::value;
+    constexpr int ROLE = decltype(role_c)::value;
     using KN = std::integral_constant<int, KIND ^ 1>;
+    // the pieces to issue in front of MFMA group g (of G) of chunk c
+    auto pieces = [&](auto c_c, auto g_c, auto G_c) __attribute__((always_inline)) {
+      constexpr int c = decltype(c_c)::value, g = decltype(g_c)::value, G = decltype(G_c)::value;
+      if constexpr (ROLE == 0) {
+        if constexpr (c8_piece(c, g, G) >= 0) issue_piece(KN{}, c8_piece(c, g, G));
+      }
+#if ZK_C8_ROLES
+      else if constexpr (ROLE == 1) {
+        constexpr int n = c8r_cnt(c);
+        static_for<n>([&](auto qc) __attribute__((always_inline)) {
+          constexpr int q = decltype(qc)::value;
+          if constexpr (q * G / n == g) issue_piece_r(KN{}, c8r_base(c) + q);
+        });
+      }
+#endif
+    };
+    using CM1 = std::integral_constant<int, -1>;
+    using GRN = std::integral_constant<int, RN>;
+    using G2RN = std::integral_constant<int, 2 * RN>;
     // X tile 0 of this step, then per W tile i: the deferred MFMA of the previous step (old wf[i], X tile RM-1 in
     // xf[1]) followed by the read of this step's W fragment INTO wf[i] — one W register set serves both steps
     ld_frag(xf[0], kind_c, xad, std::integral_constant<int, 0>{});
     static_for<RN>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      if (c8_piece(-1, i, RN) >= 0) issue_piece(KN{}, c8_piece(-1, i, RN));
+      pieces(CM1{}, ic, GRN{});
       mma(KN{}, H0{}, acc[i][RM - 1], wf[i], xf[1]);      // (very first step: zero fragments)
       mma(KN{}, H1{}, acc[i][RM - 1], wf[i], xf[1]);
       ld_frag(wf[i], kind_c, wad, ic);
@@ -424,27 +552,33 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
       else
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xf[j & 1].a), "+v"(xf[j & 1].b));
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < RN; ++i) {
-        constexpr int G = KIND == 1 ? RN : 2 * RN;
-        if (c8_piece(j, i, G) >= 0) issue_piece(KN{}, c8_piece(j, i, G));
+      static_for<RN>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (KIND == 1) pieces(jc, ic, GRN{}); else pieces(jc, ic, G2RN{});
         mma(kind_c, H0{}, acc[i][j], wf[i], xf[j & 1]);
-      }
+      });
       if constexpr (KIND == 0) {
-#pragma unroll
-        for (int i = 0; i < RN; ++i) {
-          if (c8_piece(j, RN + i, 2 * RN) >= 0) issue_piece(KN{}, c8_piece(j, RN + i, 2 * RN));
+        static_for<RN>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          pieces(jc, std::integral_constant<int, RN + i>{}, G2RN{});
           mma(kind_c, H1{}, acc[i][j], wf[i], xf[j & 1]);
-        }
+        });
       }
       __builtin_amdgcn_sched_barrier(0);
     });
+#ifdef ZK_C8_PF2
+    pf_issue(KN{});
+#endif
     advance_load(KN{});
     if (KIND == 1) {
       if (++c_k == nk) { c_k = 0; epi_pending = true; }
     }
     // the next step must have landed; X tile RM-1 of this step (xf[1]) and wf[] are in registers
+#ifdef ZK_C8_PF2
+    wait_vmcnt<1>();
+#else
     wait_vmcnt<0>();
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[1].a), "+v"(xf[1].b) : : "memory");      // X tile RM-1 is in xf[1]
     __builtin_amdgcn_s_barrier();
   };
@@ -452,10 +586,24 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 #pragma unroll
   for (int i = 0; i < RN; ++i) wf[i].a = wf[i].b = i4v_t{0, 0, 0, 0};
   xf[1].a = xf[1].b = i4v_t{0, 0, 0, 0};
-  for (int c_step = 0; c_step < total; c_step += 2) {
-    step(K0{});
-    step(K1{});
+#if ZK_C8_ROLES
+  if (is_loader) {
+    for (int c_step = 0; c_step < total; c_step += 2) {
+      step(K0{}, std::integral_constant<int, 1>{});
+      step(K1{}, std::integral_constant<int, 1>{});
+    }
+  } else {
+    for (int c_step = 0; c_step < total; c_step += 2) {
+      step(K0{}, std::integral_constant<int, 2>{});
+      step(K1{}, std::integral_constant<int, 2>{});
+    }
   }
+#else
+  for (int c_step = 0; c_step < total; c_step += 2) {
+    step(K0{}, K0{});
+    step(K1{}, K0{});
+  }
+#endif
   // deferred tile of the last step (kind 1)
 #pragma unroll
   for (int i = 0; i < RN; ++i) mma(K1{}, H0{}, acc[i][RM - 1], wf[i], xf[1]);
@@ -464,7 +612,11 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 
 template <int EPI>
 void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
+#ifdef ZK_C8_PF2
+  constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144 + 8 * 512 + 8 * 256;
+#else
   constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144 + 8 * 512;
+#endif
   auto k = gemm_c8_kernel<EPI>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
