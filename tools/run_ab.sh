@@ -1,2 +1,3 @@
 mkdir -p gpurun_out
-timeout -k 10 400 python tools/gemm_ab_multi.py 512 5 base,pf3d2,pf3d4,sym,pf3d3sym > gpurun_out/r5e_pf3.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/r5j_tests.log 2>&1 &&
+timeout -k 10 400 python bench.py --steps 10 > gpurun_out/r5j_bench.json 2> gpurun_out/r5j_bench.err

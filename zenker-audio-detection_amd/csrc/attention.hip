@@ -59,6 +59,10 @@ constexpr int NKT = (S_ + KT - 1) / KT; // 19
                          // images in 3-deep rings are 96 KiB), half the staging pieces per wave of the 4-wave form (same speed)
 #endif
 constexpr int NW = ZK_ATT_NW;
+#ifndef ZK_ATT_STAGGER
+#define ZK_ATT_STAGGER 1      // waves 4-7 run half an iteration behind their SIMD partners (see "staggered waves" below); 0 = lockstep form
+#endif
+constexpr int NVS = ZK_ATT_STAGGER ? 4 : 3;      // V ring slots (the late waves read V(t-1) while V(t+2) is being staged)
 constexpr int QT = 32 * NW;             // query rows per workgroup
 constexpr int TILE_B = KT * 128;        // bytes of one [64][64] fp16 image
 
@@ -106,15 +110,26 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   const int q_ld = q_row < S_ ? q_row : S_ - 1;
   h8_t qh[4], ql[(SPLIT && !C8) ? 4 : 1];      // ql: q's fp16 lo fragments, kept only where the 3-term split reads them later
   i8v_t qc[C8 ? 2 : 1];      // C8: q' for the two 64-byte-deep fp8 MFMAs (ks = 2t, 2t+1)
+  // The eight 16-byte loads are issued here, all at once; their scaling / re-splitting happens behind the issue of the
+  // prologue's K/V staging pieces (q_prepare below), so that ONE memory round trip covers q, K(0..2) and V(0..1) — the
+  // earlier order (load q, convert, then stage) paid three in a row per workgroup, with nothing else resident on the CU.
+  h8_t qraw_h[4], qraw_l[SPLIT ? 4 : 1];
   {
     const size_t off = (tok0 + q_ld) * QKV_LD + head * ZK_HEAD_DIM + 8 * half;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qh[ks] = *(const h8_t*)(qkv_hi + off + ks * 16);
+      qraw_h[ks] = *(const h8_t*)(qkv_hi + off + ks * 16);
+      if constexpr (SPLIT) qraw_l[ks] = *(const h8_t*)(qkv_lo + off + ks * 16);
+    }
+  }
+  auto q_prepare = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qh[ks] = qraw_h[ks];
       // q's lo fragment of this k-step lives in a local: C8 needs it only here (ql[] then has ONE element, and indexing
       // it with ks would run past its end), the 3-term split keeps the re-split value in ql[ks] below
       h8_t qlo = {};
-      if constexpr (SPLIT) qlo = *(const h8_t*)(qkv_lo + off + ks * 16);
+      if constexpr (SPLIT) qlo = qraw_l[ks];
       // fold the softmax scale and the change to the log2 domain into q once: q <- q * (d^-1/2 * log2 e)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
         }
       }
     }
-  }
+  };
 
   // ---- K/V staging: LDS-DMA (global_load_lds_dwordx4) into 3-deep rings ----
   // The loop is software-pipelined by one tile: iteration t multiplies K(t+1)·Qᵀ BESIDE the softmax of tile t (the
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
     return (const char*)(((unsigned long long)hi << 32) | lo);
   };
-  // LDS: K ring = 3 x NKIMG images at 0, V ring = 3 x NVIMG images behind it
+  // LDS: K ring = 3 x NKIMG images at 0, V ring = NVS x NVIMG images behind it
   constexpr int KBUF_B = NKIMG * TILE_B, VBUF_B = NVIMG * TILE_B;
   constexpr int V_OFF = 3 * KBUF_B;
   auto dma = [&](const char* gbase, unsigned off, char* lds) __attribute__((always_inline)) {
@@ -247,9 +262,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     static_assert(LA * 2 + 2 <= 15, "lgkmcnt is a 4-bit counter");
     return n;
   };
-  auto load_group = [&](auto gc) __attribute__((always_inline)) {
+  // (fic: which fragment register set — the position of the group in the wave's slot order modulo LA + 1)
+  auto load_group_at = [&](auto gc, auto fic) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value;
-    kf_t& f = fr[g % (LA + 1)];
+    kf_t& f = fr[decltype(fic)::value];
     if constexpr (g < NG_QK) {
       if constexpr (C8) {
         constexpr int kb = g & 1, i = g >> 1;      // the two 32-key blocks alternate: two independent accumulator chains
@@ -278,19 +294,25 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       f.a = __builtin_shufflevector(t0, t1, 0, 1, 2, 3);
     }
   };
+  auto load_group = [&](auto gc) __attribute__((always_inline)) {
+    load_group_at(gc, std::integral_constant<int, decltype(gc)::value % (LA + 1)>{});
+  };
   // the fragment of group g is in its registers (see above); names them so that no MFMA moves in front of the wait
-  auto wait_group = [&](auto gc, auto n_c) __attribute__((always_inline)) {
+  auto wait_group_at = [&](auto gc, auto fic, auto n_c) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value;
-    kf_t& f = fr[g % (LA + 1)];
+    kf_t& f = fr[decltype(fic)::value];
     if constexpr (nreads(g) == 2 && g < NG_QK)
       asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.a), "+v"(f.b) : "n"(decltype(n_c)::value));
     else
       asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f.a) : "n"(decltype(n_c)::value));
   };
+  auto wait_group = [&](auto gc, auto n_c) __attribute__((always_inline)) {
+    wait_group_at(gc, std::integral_constant<int, decltype(gc)::value % (LA + 1)>{}, n_c);
+  };
   // the MFMAs of score group g into sn (scores of the next tile minus the running max)
-  auto mma_group = [&](auto gc, f16_t (&sn)[2]) __attribute__((always_inline)) {
+  auto mma_group_at = [&](auto gc, auto fic, f16_t (&sn)[2]) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value;
-    const kf_t& f = fr[g % (LA + 1)];
+    const kf_t& f = fr[decltype(fic)::value];
     if constexpr (C8) {
       constexpr int kb = g & 1, i = g >> 1;      // the two 32-key blocks alternate: two independent accumulator chains
       if constexpr (i < 2) {
@@ -313,6 +335,9 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       }
     }
   };
+  auto mma_group = [&](auto gc, f16_t (&sn)[2]) __attribute__((always_inline)) {
+    mma_group_at(gc, std::integral_constant<int, decltype(gc)::value % (LA + 1)>{}, sn);
+  };
   // first and count of the 32 exponentials that ride in score slot g
   auto exp_count = [](int g) constexpr { return C8 ? ((g >> 1) < 2 ? 4 : 2) : 4; };
   auto exp_first = [exp_count](int g) constexpr {
@@ -330,6 +355,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     dma_piece(pc, 1, 1, 1, 1);
     if (pc < PPI * NKIMG) dma_piece(pc, 2, 2, 0, 0);
   }
+  __builtin_amdgcn_sched_barrier(0);      // (the pieces are in flight before q's vector work starts)
+  q_prepare();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -404,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       if (pc & 1) return;      // (timing probe: half of the staging, wrong results)
 #endif
 #if !(ZK_ATT_ABL & 1)
-      dma_piece(pc, kt + 3, s0, kt + 2, s2);
+      dma_piece(pc, kt + 3, s0, kt + 2, NVS == 4 ? ((kt + 2) & 3) : s2);
 #endif
     };
     if constexpr (!LAST) {
@@ -416,7 +443,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) ka[ks] = kofs[ks] + (unsigned)(s1 * KBUF_B);      // K(t+1)
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) va[mb] = vofs[mb] + (unsigned)(s0 * VBUF_B);       // V(t)
+    for (int mb = 0; mb < 2; ++mb) va[mb] = vofs[mb] + (unsigned)((NVS == 4 ? (kt & 3) : s0) * VBUF_B);       // V(t)
 
     if (wave_active) {
       // deferred rescale (rare, wave-uniform): before the next tile's scores are started with the running max
@@ -476,9 +503,147 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       kslot = s1;
     }
   };
+
+#if ZK_ATT_STAGGER
+  // ---- staggered waves (MI355X guide, "two waves per SIMD", item 9) ----
+  // Waves 4-7 — the SIMD partners of waves 0-3 — run the SAME slot sequence half an iteration late: their barrier falls
+  // between the score half and the PV half, so the interval between two barriers is  PV(t-1) ‖ max(s_t),  QK(t+1) ‖ exp(s_t)
+  // for them while their partners run  QK(t+1) ‖ exp(s_t),  PV(t) ‖ max(s_t+1):  one wave's MFMA-only PV slots beside the
+  // other's exp-heavy score slots instead of both waves in the same phase.  Costs: P(t-1) lives across the barrier (it is
+  // live anyway), a fourth V ring slot (V(t-1) is read while V(t+2) lands), one more instantiation of the slot sequence.
+  h8_t pfr[2][2];      // the late waves' P tile (written in the score half, read in the next interval's PV half)
+  // position p of the late waves' slot order -> group
+  auto rot_g = [](int p) constexpr { return p < NG_PV ? NG_QK + p : p - NG_PV; };
+  auto rot_reads_after = [nreads, rot_g](int p, int n_pos) constexpr {
+    int n = 0;
+    for (int j = p + 1; j <= p + LA && j < n_pos; ++j) n += nreads(rot_g(j));
+    return n;
+  };
+  // the 32-lane exchange of the row maximum as a VALU swap (ds_bpermute would count in lgkmcnt, in the middle of the slots)
+  auto xhalf_max = [](float v) __attribute__((always_inline)) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  };
+  // One interval of a late wave.  FIRST: interval 0 (score half only: QK(1) ‖ exp(s_0)); FINAL: the part behind the last
+  // barrier (PV(NKT-2) ‖ max(s_NKT-1) with the padding keys masked, exp(s_NKT-1), PV(NKT-1)); otherwise interval kt =
+  // PV(kt-1) ‖ max(sc = s_kt), [rescale], QK(kt+1) -> sn ‖ exp(sc) -> pfr.
+  auto interval_late = [&](int kt, f16_t (&sc)[2], f16_t (&sn)[2], auto first_c, auto final_c) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_c)::value, FINAL = decltype(final_c)::value;
+    constexpr int P0 = FIRST ? NG_PV : 0;                 // first position executed
+    constexpr int P1 = FINAL ? NG_PV : NSLOT;             // one past the last
+    const int s0 = kslot, s1 = s0 == 2 ? 0 : s0 + 1;      // kt%3, (kt+1)%3
+    auto stage_piece = [&](int pc) __attribute__((always_inline)) {
+#if !(ZK_ATT_ABL & 1)
+      dma_piece(pc, kt + 3, s0, kt + 2, (kt + 2) & 3);
+#endif
+    };
+    if constexpr (!FINAL) {
+      if (!wave_active) {
+#pragma unroll
+        for (int pc = 0; pc < PER_ITER; ++pc) stage_piece(pc);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[ks] = kofs[ks] + (unsigned)(s1 * KBUF_B);                // K(kt+1)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) va[mb] = vofs[mb] + (unsigned)(((kt - 1) & 3) * VBUF_B);    // V(kt-1)
+    if (wave_active) {
+      float psum = 0.f, mxp = -3.0e38f;
+      static_for<LA>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int p = P0 + decltype(ic)::value;
+        if constexpr (p < P1) load_group_at(std::integral_constant<int, rot_g(p)>{}, std::integral_constant<int, p % (LA + 1)>{});
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<P1 - P0>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int p = P0 + decltype(ic)::value, g = rot_g(p);
+        using FI = std::integral_constant<int, p % (LA + 1)>;
+        if constexpr (!FINAL) {
+          // the interval's staging pieces, spread over its positions (FIRST has only the score half to put them in)
+          constexpr int q = p - P0, every = (P1 - P0) / PER_ITER;
+          if constexpr (q % every == every - 1 && q / every < PER_ITER) { if (wave_active) stage_piece(q / every); }
+        }
+        if constexpr (p + LA < P1)
+          load_group_at(std::integral_constant<int, rot_g(p + LA)>{}, std::integral_constant<int, (p + LA) % (LA + 1)>{});
+        wait_group_at(std::integral_constant<int, g>{}, FI{}, std::integral_constant<int, rot_reads_after(p, P1)>{});
+        if constexpr (g >= NG_QK) {
+          constexpr int pv = g - NG_QK, v = VL ? pv / 2 : pv, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
+          constexpr int EPS = 32 / NG_PV;
+          oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], oacc[mb], 0, 0, 0);
+#pragma unroll
+          for (int e = EPS * pv; e < EPS * pv + EPS; ++e) {
+            const int kbn = e >> 4, r = e & 15;
+            if constexpr (FINAL) {
+              const int key = (NKT - 1) * KT + kbn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              if (key >= S_) sc[kbn][r] = -1e30f;
+            }
+            mxp = fmaxf(mxp, sc[kbn][r]);
+          }
+          if constexpr (pv == NG_PV - 1) {      // behind the last PV slot: the running maximum moves before the scores start
+            __builtin_amdgcn_sched_barrier(0);
+            const float mx = xhalf_max(mxp);
+            if (!__all(mx <= RESCALE_THR)) {
+              const float delta = fmaxf(mx, 0.f);
+              rescale(sc, delta, __builtin_amdgcn_exp2f(-delta));
+            }
+          }
+        } else {
+          mma_group_at(std::integral_constant<int, g>{}, FI{}, sn);
+#pragma unroll
+          for (int e = exp_first(g); e < exp_first(g) + exp_count(g); e += 2) psum = exp_pair(sc, pfr, e, psum);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (FINAL) {      // exp(s_NKT-1) with nothing beside it, then PV(NKT-1)
+#pragma unroll
+        for (int e = 0; e < 32; e += 2) psum = exp_pair(sc, pfr, e, psum);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) va[mb] = vofs[mb] + (unsigned)((kt & 3) * VBUF_B);       // V(kt)
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<LA>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int p = decltype(ic)::value;
+          load_group_at(std::integral_constant<int, NG_QK + p>{}, std::integral_constant<int, p % (LA + 1)>{});
+        });
+        static_for<NG_PV>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int p = decltype(ic)::value, g = NG_QK + p;
+          using FI = std::integral_constant<int, p % (LA + 1)>;
+          if constexpr (p + LA < NG_PV)
+            load_group_at(std::integral_constant<int, g + LA>{}, std::integral_constant<int, (p + LA) % (LA + 1)>{});
+          wait_group_at(std::integral_constant<int, g>{}, FI{}, std::integral_constant<int, rot_reads_after(p, NG_PV)>{});
+          constexpr int v = VL ? p / 2 : p, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
+          oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], oacc[mb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      l_run += psum;
+    }
+    if constexpr (!FINAL) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_ITER) : "memory");
+#if !(ZK_ATT_ABL & 2)
+      __builtin_amdgcn_s_barrier();
+#endif
+      kslot = s1;
+    }
+  };
+#endif
   static_assert((NKT - 1) % 2 == 0, "the tile loop runs in pairs (the two score tiles swap roles)");
   using F = std::false_type;
   using T = std::true_type;
+#if ZK_ATT_STAGGER
+#ifdef ZK_ATT_STG_PRIO      // probe: static priority for the late (1) or the early (2) half
+  if ((ZK_ATT_STG_PRIO == 1) == (wave >= NW / 2)) __builtin_amdgcn_s_setprio(1);
+#endif
+  if (wave >= NW / 2) {      // (wave-uniform; both branches pass the same NKT-1 barriers)
+    interval_late(0, sA, sB, T{}, F{});
+    for (int kt = 1; kt < NKT - 2; kt += 2) {
+      interval_late(kt, sB, sA, F{}, F{});
+      interval_late(kt + 1, sA, sB, F{}, F{});
+    }
+    static_assert((NKT - 3) % 2 == 0, "the late waves' loop ends on interval NKT-3 with the roles (sA, sB)");
+    interval_late(NKT - 2, sB, sA, F{}, F{});
+    interval_late(NKT - 1, sA, sB, F{}, T{});
+  } else
+#endif
+  {
   for (int kt = 0; kt < NKT - 3; kt += 2) {
     iteration(kt, sA, sB, F{}, F{});
     iteration(kt + 1, sB, sA, F{}, F{});
@@ -486,6 +651,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   iteration(NKT - 3, sA, sB, F{}, F{});
   iteration(NKT - 2, sB, sA, F{}, T{});
   iteration(NKT - 1, sA, sB, T{}, F{});
+  }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the surplus pieces of the last iterations)
   // ---- finalize: O / l.  A lane holds 4 consecutive d of ITS query row per register group, i.e. stored directly a wave
@@ -564,7 +730,8 @@ void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit
 #else
   constexpr int NIMG_SPLIT = 4;
 #endif
-  if (nsplit == 2) go(attention_kernel<2>, 3 * NIMG_SPLIT * TILE_B);
-  else if (nsplit == 3) go(attention_kernel<3>, 3 * NIMG_SPLIT * TILE_B);
-  else go(attention_kernel<1>, 3 * 2 * TILE_B);
+  // (K ring of 3 slots x 2 images in the split modes, V ring of NVS slots x (NIMG_SPLIT - 2) images)
+  if (nsplit == 2) go(attention_kernel<2>, (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B);
+  else if (nsplit == 3) go(attention_kernel<3>, (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B);
+  else go(attention_kernel<1>, (3 + NVS) * TILE_B);
 }
