@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/r5j_tests.log 2>&1 &&
-timeout -k 10 400 python bench.py --steps 10 > gpurun_out/r5j_bench.json 2> gpurun_out/r5j_bench.err
+timeout -k 10 300 python bench.py --steps 5 --headline-only --micro-batch 1024 > gpurun_out/r5l_mb1024.json 2> gpurun_out/r5l_mb1024.err &&
+timeout -k 10 300 python bench.py --steps 5 --headline-only --micro-batch 512 > gpurun_out/r5l_mb512.json 2> gpurun_out/r5l_mb512.err

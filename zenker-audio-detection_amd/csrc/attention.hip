@@ -656,13 +656,15 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the surplus pieces of the last iterations)
   // ---- finalize: O / l.  A lane holds 4 consecutive d of ITS query row per register group, i.e. stored directly a wave
   // instruction would write 16-byte fragments of 32 different rows (measured: 10 % of the kernel).  The tile goes
-  // through LDS instead (the K ring is free now: every wave is past its last fragment read at the barrier) and leaves
+  // through LDS instead (a strip of its own behind the rings) and leaves
   // as whole 128-byte rows, 8 lanes per row.
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
-  __builtin_amdgcn_s_barrier();
   constexpr int O_STR = 144;                       // bytes per staged row (128 + pad: conflict-free 8-byte writes)
-  char* stg = smem + wave * (32 * O_STR);          // this wave's 32 rows
+  // (the staging strip lies BEHIND the rings: no barrier in front of it, so the early half stores while the late half of
+  // a staggered workgroup is still in its last PV slots; aliased into the K ring it cost a barrier and half an iteration
+  // of idle early waves per workgroup)
+  char* stg = smem + 3 * KBUF_B + NVS * VBUF_B + wave * (32 * O_STR);          // this wave's 32 rows
   const int rd_row = lane >> 3, rd_ch = lane & 7;
   const bool act = wave_active && (!(ZK_ATT_ABL & 16) || lo_fmt == 12345);      // (16: a never-true runtime test keeps the work alive)
   const size_t orow0 = (tok0 + (size_t)(qt * QT + wave * 32)) * ZK_HIDDEN + head * ZK_HEAD_DIM;
@@ -730,8 +732,9 @@ void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit
 #else
   constexpr int NIMG_SPLIT = 4;
 #endif
-  // (K ring of 3 slots x 2 images in the split modes, V ring of NVS slots x (NIMG_SPLIT - 2) images)
-  if (nsplit == 2) go(attention_kernel<2>, (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B);
-  else if (nsplit == 3) go(attention_kernel<3>, (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B);
-  else go(attention_kernel<1>, (3 + NVS) * TILE_B);
+  // (K ring of 3 slots x 2 images in the split modes, V ring of NVS slots x (NIMG_SPLIT - 2) images, output staging strip)
+  constexpr int STG_B = NW * 32 * 144;
+  if (nsplit == 2) go(attention_kernel<2>, (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B + STG_B);
+  else if (nsplit == 3) go(attention_kernel<3>, (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B + STG_B);
+  else go(attention_kernel<1>, (3 + NVS) * TILE_B + STG_B);
 }
