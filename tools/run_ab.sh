@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-timeout -k 10 300 python bench.py --steps 5 --headline-only --micro-batch 1024 > gpurun_out/r5l_mb1024.json 2> gpurun_out/r5l_mb1024.err &&
-timeout -k 10 300 python bench.py --steps 5 --headline-only --micro-batch 512 > gpurun_out/r5l_mb512.json 2> gpurun_out/r5l_mb512.err
+ZKAST_LIB=$PWD/zenker-audio-detection_amd/zkast/libzkast_per2.so timeout -k 10 200 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "attention" > gpurun_out/r5n_tests.log 2>&1 &&
+timeout -k 10 300 python tools/attn_ab_multi.py 512 7 prev,per0,per2 > gpurun_out/r5n_att_ab.log 2>&1

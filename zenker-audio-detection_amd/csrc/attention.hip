@@ -62,6 +62,9 @@ constexpr int NW = ZK_ATT_NW;
 #ifndef ZK_ATT_STAGGER
 #define ZK_ATT_STAGGER 1      // waves 4-7 run half an iteration behind their SIMD partners (see "staggered waves" below); 0 = lockstep form
 #endif
+#ifndef ZK_ATT_PERSIST
+XX
+#endif
 constexpr int NVS = ZK_ATT_STAGGER ? 4 : 3;      // V ring slots (the late waves read V(t-1) while V(t+2) is being staged)
 constexpr int QT = 32 * NW;             // query rows per workgroup
 constexpr int TILE_B = KT * 128;        // bytes of one [64][64] fp16 image
@@ -91,37 +94,57 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   const int wave = tid >> 6;
   const int half = lane >> 5;
 
-  // XCD-aware bijective remap: the 10 query tiles of one (window, head) share K/V -> keep them on one XCD.
+  // XCD-aware bijective remap: the query tiles of one (window, head) share K/V -> keep them on one XCD.  XCD x (= block
+  // index mod 8 under round-robin placement: speed only) owns a contiguous share of the nwg items.
   const int nwg = q_tiles * ZK_HEADS * n_windows;
-  int wg;
+  int qt, head;
+  size_t tok0;
+  auto set_item = [&](int wg) __attribute__((always_inline)) {
+    qt = wg % q_tiles;
+    head = (wg / q_tiles) % ZK_HEADS;
+    tok0 = (size_t)(wg / (q_tiles * ZK_HEADS)) * S_;
+  };
+#if ZK_ATT_PERSIST
+  // Persistent form: the workgroup walks items j, j + per, j + 2 per, ... of its XCD's share (at any moment the CUs of an
+  // XCD work on neighbouring items, as the hardware's own dispatch order had it).  The NEXT item's q loads and K/V
+  // prologue pieces are issued in front of THIS item's output stores, so the memory round trip of a prologue, the store
+  // tail and the workgroup launch no longer sit exposed on a CU that holds only this one workgroup.
+  const int x_q = nwg >> 3, x_r = nwg & 7, x_id = (int)blockIdx.x & 7, x_per = (int)gridDim.x >> 3;
+  const int x_start = x_id < x_r ? x_id * (x_q + 1) : x_r * (x_q + 1) + (x_id - x_r) * x_q;
+  const int x_count = x_q + (x_id < x_r ? 1 : 0);
+  int it_idx = (int)blockIdx.x >> 3;
+  if (it_idx >= x_count) return;
+  auto item_wg = [&](int idx) __attribute__((always_inline)) { return x_start + (rev ? x_count - 1 - idx : idx); };      // rev: last item first
+  set_item(item_wg(it_idx));
+#else
   {
     const int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;      // rev: last window first
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    set_item((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx);
   }
-  const int qt = wg % q_tiles;
-  const int head = (wg / q_tiles) % ZK_HEADS;
-  const int win = wg / (q_tiles * ZK_HEADS);
-  const size_t tok0 = (size_t)win * S_;
+#endif
 
   // ---- Q fragments (B operand: lane holds Q[q = lane&31][d = 16ks + 8*half + j]) ----
-  const int q_row = qt * QT + wave * 32 + (lane & 31);
-  const int q_ld = q_row < S_ ? q_row : S_ - 1;
   h8_t qh[4], ql[(SPLIT && !C8) ? 4 : 1];      // ql: q's fp16 lo fragments, kept only where the 3-term split reads them later
   i8v_t qc[C8 ? 2 : 1];      // C8: q' for the two 64-byte-deep fp8 MFMAs (ks = 2t, 2t+1)
   // The eight 16-byte loads are issued here, all at once; their scaling / re-splitting happens behind the issue of the
   // prologue's K/V staging pieces (q_prepare below), so that ONE memory round trip covers q, K(0..2) and V(0..1) — the
   // earlier order (load q, convert, then stage) paid three in a row per workgroup, with nothing else resident on the CU.
   h8_t qraw_h[4], qraw_l[SPLIT ? 4 : 1];
-  {
-    const size_t off = (tok0 + q_ld) * QKV_LD + head * ZK_HEAD_DIM + 8 * half;
+  auto q_issue = [&]() __attribute__((always_inline)) {      // (of the item set_item() selected)
+    int ln;      // (read here, not taken from the kernel's `lane`: see the output path)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int q_row = qt * QT + wave * 32 + (ln & 31);
+    const int q_ld = q_row < S_ ? q_row : S_ - 1;
+    const size_t off = (tok0 + q_ld) * QKV_LD + head * ZK_HEAD_DIM + 8 * (ln >> 5);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       qraw_h[ks] = *(const h8_t*)(qkv_hi + off + ks * 16);
       if constexpr (SPLIT) qraw_l[ks] = *(const h8_t*)(qkv_lo + off + ks * 16);
     }
-  }
+  };
+  q_issue();
   auto q_prepare = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -348,13 +371,21 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
 
   // a wave whose 32 query rows all lie beyond the sequence (the last query tile holds 62 of 128 rows: waves 2 and 3)
   // only takes part in the K/V staging and the barriers — its SIMD time goes to the other resident workgroup
-  const bool wave_active = __builtin_amdgcn_readfirstlane(qt * QT + wave * 32) < (row_limit < S_ ? row_limit : S_);
+  bool wave_active;
+  auto kv_prologue = [&]() __attribute__((always_inline)) {      // K(0..2), V(0..1) of the item set_item() selected
 #pragma unroll
-  for (int pc = 0; pc < PER_ITER; ++pc) {
-    dma_piece(pc, 0, 0, 0, 0);
-    dma_piece(pc, 1, 1, 1, 1);
-    if (pc < PPI * NKIMG) dma_piece(pc, 2, 2, 0, 0);
-  }
+    for (int pc = 0; pc < PER_ITER; ++pc) {
+      dma_piece(pc, 0, 0, 0, 0);
+      dma_piece(pc, 1, 1, 1, 1);
+      if (pc < PPI * NKIMG) dma_piece(pc, 2, 2, 0, 0);
+    }
+  };
+  kv_prologue();
+  for (;;) {      // one item per pass (ZK_ATT_PERSIST = 0: a single pass)
+  wave_active = __builtin_amdgcn_readfirstlane(qt * QT + wave * 32) < (row_limit < S_ ? row_limit : S_);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; negm[i] = 0.f; }
+  m_run = 0.f; l_run = 0.f;
   __builtin_amdgcn_sched_barrier(0);      // (the pieces are in flight before q's vector work starts)
   q_prepare();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -665,18 +696,37 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   // a staggered workgroup is still in its last PV slots; aliased into the K ring it cost a barrier and half an iteration
   // of idle early waves per workgroup)
   char* stg = smem + 3 * KBUF_B + NVS * VBUF_B + wave * (32 * O_STR);          // this wave's 32 rows
-  const int rd_row = lane >> 3, rd_ch = lane & 7;
+  // (every per-lane value of the output path derives from a lane index read HERE: computed from the kernel's `lane` they
+  // are invariants of the item loop, hipcc hoists them in front of it and spills them across the whole tile loop)
+  int ln;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+  const int rd_row = ln >> 3, rd_ch = ln & 7, e_half = ln >> 5, e_row = ln & 31;
   const bool act = wave_active && (!(ZK_ATT_ABL & 16) || lo_fmt == 12345);      // (16: a never-true runtime test keeps the work alive)
-  const size_t orow0 = (tok0 + (size_t)(qt * QT + wave * 32)) * ZK_HIDDEN + head * ZK_HEAD_DIM;
+  const int row_base = qt * QT + wave * 32;
+  const size_t orow0 = (tok0 + (size_t)row_base) * ZK_HIDDEN + head * ZK_HEAD_DIM;
+#if ZK_ATT_PERSIST
+  // next item: its q loads and K/V prologue pieces go out in front of this item's stores.  The barrier: every wave is past
+  // its last fragment read, the rings may be overwritten.
+  it_idx += x_per;
+  const bool more = it_idx < x_count;
+  __builtin_amdgcn_s_barrier();
+  if (more) {
+    set_item(item_wg(it_idx));
+#if ZK_ATT_PERSIST == 1
+    q_issue();
+#endif
+    kv_prologue();
+  }
+#endif
   auto flush = [&](half_t* plane) __attribute__((always_inline)) {      // staged rows -> global, 4 x (8 rows x 128 B)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int r = rd_row + 8 * t;
       const h8_t v = *(const h8_t*)(stg + r * O_STR + rd_ch * 16);
 #ifdef ZK_ATT_NT
-      if (qt * QT + wave * 32 + r < S_) __builtin_nontemporal_store(v, (h8_t*)(plane + orow0 + (size_t)r * ZK_HIDDEN + rd_ch * 8));
+      if (row_base + r < S_) __builtin_nontemporal_store(v, (h8_t*)(plane + orow0 + (size_t)r * ZK_HIDDEN + rd_ch * 8));
 #else
-      if (qt * QT + wave * 32 + r < S_) *(h8_t*)(plane + orow0 + (size_t)r * ZK_HIDDEN + rd_ch * 8) = v;
+      if (row_base + r < S_) *(h8_t*)(plane + orow0 + (size_t)r * ZK_HIDDEN + rd_ch * 8) = v;
 #endif
     }
   };
@@ -686,7 +736,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int d = 32 * mb + 8 * rg + 4 * half;
+        const int d = 32 * mb + 8 * rg + 4 * e_half;
         h4_t hi;
         float v[4];
 #pragma unroll
@@ -695,7 +745,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
           zk_pin(v[j]);
           hi[j] = (half_t)v[j];
         }
-        *(h4_t*)(stg + (lane & 31) * O_STR + d * 2) = hi;
+        *(h4_t*)(stg + e_row * O_STR + d * 2) = hi;
         if (o_lo) lo4[mb][rg] = zk_lo4(v, hi, lo_fmt);
       }
     flush(o_hi);
@@ -703,10 +753,19 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) *(h4_t*)(stg + (lane & 31) * O_STR + (32 * mb + 8 * rg + 4 * half) * 2) = lo4[mb][rg];
+        for (int rg = 0; rg < 4; ++rg) *(h4_t*)(stg + e_row * O_STR + (32 * mb + 8 * rg + 4 * e_half) * 2) = lo4[mb][rg];
       flush(o_lo);
     }
   }
+#if ZK_ATT_PERSIST
+  if (!more) break;
+#if ZK_ATT_PERSIST == 2      // (q loads behind the stores: their 32 registers do not overlap the output path's)
+  q_issue();
+#endif
+#else
+  break;
+#endif
+  }      // item loop
 }
 
 }  // namespace
@@ -725,7 +784,12 @@ void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit
       (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr[nsplit & 3] = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * NW), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, wg_tiles, out.lo_fmt, row_limit, rev);
+#if ZK_ATT_PERSIST
+    const int pgrid = grid < 256 ? ((grid + 7) / 8) * 8 : 256;      // one workgroup per CU (LDS), a multiple of the 8 XCDs
+#else
+    const int pgrid = grid;
+#endif
+    hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(64 * NW), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, wg_tiles, out.lo_fmt, row_limit, rev);
   };
 #ifdef ZK_ATT_NO_VL
   constexpr int NIMG_SPLIT = 3;
