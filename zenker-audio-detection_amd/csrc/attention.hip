@@ -63,7 +63,8 @@ constexpr int NW = ZK_ATT_NW;
 #define ZK_ATT_STAGGER 1      // waves 4-7 run half an iteration behind their SIMD partners (see "staggered waves" below); 0 = lockstep form
 #endif
 #ifndef ZK_ATT_PERSIST
-XX
+#define ZK_ATT_PERSIST 0      // probe (measured +1.0 % in f16c8, -0.5 % in f16x3: profiles/r03_attention_stagger_ab.txt): 1 / 2 = one workgroup per
+                              // CU walks its XCD's share of the (window, head, query tile) items (2: q loads behind the stores, no spills)
 #endif
 constexpr int NVS = ZK_ATT_STAGGER ? 4 : 3;      // V ring slots (the late waves read V(t-1) while V(t+2) is being staged)
 constexpr int QT = 32 * NW;             // query rows per workgroup
