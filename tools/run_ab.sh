@@ -1,3 +1,6 @@
 mkdir -p gpurun_out
-ZKAST_LIB=$PWD/zenker-audio-detection_amd/zkast/libzkast_per2.so timeout -k 10 200 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "attention" > gpurun_out/r5n_tests.log 2>&1 &&
-timeout -k 10 300 python tools/attn_ab_multi.py 512 7 prev,per0,per2 > gpurun_out/r5n_att_ab.log 2>&1
+OLD=$PWD/zenker-audio-detection_amd/zkast/libzkast_r3start.so
+for i in 1 2 3; do
+ZKAST_LIB=$OLD timeout -k 10 200 python bench.py --steps 8 --headline-only > gpurun_out/r3e_old_$i.json 2> gpurun_out/r3e_old_$i.err || exit 1
+timeout -k 10 200 python bench.py --steps 8 --headline-only > gpurun_out/r3e_new_$i.json 2> gpurun_out/r3e_new_$i.err || exit 1
+done
