@@ -27,6 +27,17 @@
 
 #include "gemm_util.h"
 
+#ifdef ZK_C8_STAMPS
+// probe builds only (tools/gemm_stamps.py): three s_memtime stamps per ring step and wave — A = every MFMA and piece of the
+// step is issued, B = the next step's data has landed (vmcnt(0)), C = the step barrier has released — written with scalar
+// stores into a ring of the last 64 steps per (workgroup, wave).  (Cprev -> A = issue phase, A -> B = data wait, B -> C =
+// waiting for the other waves.)  The stamps cost three SMEM round trips per step; nothing else in the kernel changes.
+__device__ unsigned zk_c8_stamp_buf[256 * 8 * 64 * 4];
+extern "C" int zkp_c8_stamps_read(unsigned* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zk_c8_stamp_buf), sizeof(zk_c8_stamp_buf));
+}
+#endif
+
 namespace {
 
 // symmetric form (ZK_C8_ROLES=0): the 8 LDS-DMA pieces a wave issues per step: 2 in the deferred tile right behind the step barrier (chunk -1), 2 in
@@ -542,9 +553,25 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
       if (++c_k == nk) { c_k = 0; epi_pending = true; }
     }
     // the next step must have landed; X tile RM-1 of this step (xf[1]) and wf[] are in registers
+#ifdef ZK_C8_STAMPS
+    unsigned long long st_a, st_b, st_c;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_a) : : "memory");
+    wait_vmcnt<0>();
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_b) : : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[1].a), "+v"(xf[1].b) : : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c) : : "memory");
+    {
+      unsigned* sp = zk_c8_stamp_buf + (size_t)((blockIdx.x * 8 + wave) * 64 + (l_step & 63)) * 4;
+      const unsigned a0 = (unsigned)st_a, b0 = (unsigned)st_b, c0 = (unsigned)st_c, id = (unsigned)l_step * 2 + KIND;
+      asm volatile("s_store_dword %1, %0, 0x0\n\ts_store_dword %2, %0, 0x4\n\ts_store_dword %3, %0, 0x8\n\ts_store_dword %4, %0, 0xc"
+                   : : "s"(sp), "s"(a0), "s"(b0), "s"(c0), "s"(id) : "memory");
+    }
+#else
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[1].a), "+v"(xf[1].b) : : "memory");      // X tile RM-1 is in xf[1]
     __builtin_amdgcn_s_barrier();
+#endif
   };
 
 #pragma unroll
@@ -572,6 +599,9 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 #pragma unroll
   for (int i = 0; i < RN; ++i) mma(K1{}, H0{}, acc[i][RM - 1], wf[i], xf[1]);
   epilogue();
+#ifdef ZK_C8_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
+#endif
 }
 
 template <int EPI>
