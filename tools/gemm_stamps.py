@@ -3,6 +3,7 @@ three s_memtime stamps per step and wave, A = all MFMAs / LDS-DMA pieces of the 
 landed (vmcnt(0)), C = step barrier released.  Prints, per build / shape / step kind / wave half, the medians of
    issue = A - C(previous step)    wait = B - A    barrier = C - B    step = C - C(previous step)      [shader cycles]
 over the last 64 steps of every (workgroup, wave); steps that carry a tile epilogue (> 1.6 x the median step) are left out.
+Also prints the clock the chip held during the launch (s_memtime against the 100 MHz s_memrealtime, per workgroup).
 usage: python tools/gemm_stamps.py <windows> <name>[,<name>...]      (libzkast_probes_<name>.so)"""
 import ctypes as C
 import os
@@ -28,10 +29,14 @@ def main():
         for sname, N, K, epi in shapes:
             ms = (C.c_float * 2)()
             mm = C.c_ulonglong(0)
-            if lib.zkp_bench_gemm_c8(M, N, K, epi, 2, 1, 1, ms, C.byref(mm)):
+            if lib.zkp_bench_gemm_c8(M, N, K, epi, 2, 40, 1, ms, C.byref(mm)):      # 80 back-to-back launches: the clock has settled
                 raise SystemExit("probe failed")
             if lib.zkp_c8_stamps_read(buf.ctypes.data_as(C.POINTER(C.c_uint))):
                 raise SystemExit("stamp read failed")
+            clk = np.zeros(256 * 4, np.uint64)
+            lib.zkp_c8_clock_read(clk.ctypes.data_as(C.POINTER(C.c_ulonglong)))
+            ck = clk.reshape(256, 4).astype(np.float64)
+            ghz = np.median((ck[:, 2] - ck[:, 0]) / np.maximum(ck[:, 3] - ck[:, 1], 1.0)) * 0.1
             e = buf.reshape(256, 8, 64, 4).astype(np.int64)
             rows = {}      # (kind, half) -> list of (issue, wait, bar, step)
             for b in range(256):
@@ -49,7 +54,10 @@ def main():
                         sel = ok & (kind == k)
                         if sel.any():
                             rows.setdefault((k, w // 4), []).append(np.stack([issue[sel], wait[sel], bar[sel], step[sel]], 1))
-            print(f"{n} {sname} (kernel {ms[1]:.3f} ms with the stamps)")
+            if not buf.any():      # -DZK_C8_STAMPS=2: clock stamps only
+                print(f"{n} {sname}: kernel {ms[1]:.3f} ms, in-kernel clock {ghz:.2f} GHz (no per-step stamps in this build)", flush=True)
+                continue
+            print(f"{n} {sname} (kernel {ms[1]:.3f} ms with the stamps; in-kernel clock {ghz:.2f} GHz = d s_memtime / d s_memrealtime x 100 MHz, median over the workgroups)")
             for (k, h), v in sorted(rows.items()):
                 v = np.concatenate(v)
                 med = np.median(v[:, 3])

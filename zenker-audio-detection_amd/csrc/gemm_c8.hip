@@ -33,8 +33,14 @@
 // stores into a ring of the last 64 steps per (workgroup, wave).  (Cprev -> A = issue phase, A -> B = data wait, B -> C =
 // waiting for the other waves.)  The stamps cost three SMEM round trips per step; nothing else in the kernel changes.
 __device__ unsigned zk_c8_stamp_buf[256 * 8 * 64 * 4];
+// per workgroup: s_memtime and s_memrealtime (100 MHz) at kernel entry and exit -> the clock the chip held under this kernel
+// (MI355X guide, DVFS give-back item 6: clock = d(memtime) / d(memrealtime) x 100 MHz)
+__device__ unsigned long long zk_c8_clock_buf[256 * 4];
 extern "C" int zkp_c8_stamps_read(unsigned* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zk_c8_stamp_buf), sizeof(zk_c8_stamp_buf));
+}
+extern "C" int zkp_c8_clock_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zk_c8_clock_buf), sizeof(zk_c8_clock_buf));
 }
 #endif
 
@@ -131,6 +137,14 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   const int my_tiles = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
   const int total = my_tiles * nk * 2;
   if (total == 0) return;
+#ifdef ZK_C8_STAMPS
+  {
+    unsigned long long t0, r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) : : "memory");
+    unsigned long long* cp = zk_c8_clock_buf + blockIdx.x * 4;
+    asm volatile("s_store_dwordx2 %1, %0, 0x0\n\ts_store_dwordx2 %2, %0, 0x8" : : "s"(cp), "s"(t0), "s"(r0) : "memory");
+  }
+#endif
 #ifndef ZK_C8_STAGGER
 #define ZK_C8_STAGGER 12
 #endif
@@ -553,7 +567,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
       if (++c_k == nk) { c_k = 0; epi_pending = true; }
     }
     // the next step must have landed; X tile RM-1 of this step (xf[1]) and wf[] are in registers
-#ifdef ZK_C8_STAMPS
+#if defined(ZK_C8_STAMPS) && ZK_C8_STAMPS == 1      // (ZK_C8_STAMPS=2: only the kernel-level clock stamps, the steps run as shipped)
     unsigned long long st_a, st_b, st_c;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_a) : : "memory");
     wait_vmcnt<0>();
@@ -600,6 +614,12 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   for (int i = 0; i < RN; ++i) mma(K1{}, H0{}, acc[i][RM - 1], wf[i], xf[1]);
   epilogue();
 #ifdef ZK_C8_STAMPS
+  {
+    unsigned long long t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) : : "memory");
+    unsigned long long* cp = zk_c8_clock_buf + blockIdx.x * 4;
+    asm volatile("s_store_dwordx2 %1, %0, 0x10\n\ts_store_dwordx2 %2, %0, 0x18" : : "s"(cp), "s"(t1), "s"(r1) : "memory");
+  }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
 #endif
 }
