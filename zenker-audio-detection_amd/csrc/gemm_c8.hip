@@ -104,8 +104,13 @@ typedef int i4v_t __attribute__((ext_vector_type(4)));
 typedef int i8v_t __attribute__((ext_vector_type(8)));
 struct frag_t { i4v_t a, b; };
 
-template <int EPI>
+// TILED (zk_gemm_args::tiled): the operand handed from FC1 to FC2 lies in k-slice-major tiles — [row block][64-k chunk][256
+// rows][128 B], the 128 bytes of a row already in the LDS image's swizzled chunk order — so that the X half of a ring step is
+// 32 KiB CONTIGUOUS in HBM (one DRAM page run instead of 256 row segments 6 KiB apart) and an LDS-DMA piece is a linear
+// kilobyte.  EPI_GELU + TILED: the epilogue writes its planes that way; EPI_RESID + TILED: the loader reads X that way.
+template <int EPI, bool TILED>
 __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
+  static_assert(!TILED || ZK_C8_ROLES, "the tiled operand form is read by the role loader only");
   constexpr int BM = 256, BN = 256, BK = 64, WM = 2, WN = 4;
   constexpr int ROWB = 128, CPR = 8, RPI = 8;
   constexpr int TM = BM / WM, TN = BN / WN;       // 128 x 64 per wave
@@ -231,12 +236,20 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
     const int k0 = l_k * BK;
     const int q = (p >> 1) & 3, h = p & 1, unit = q * 8 + (wave & 3) + 4 * h;
     const bool isw = p >= 8;
+    if (EPI == ZK_EPI_RESID && TILED && !isw) {      // (p is a constant at every call site: no branch is emitted)
+      unsigned l16;      // lane·16, read here instead of kept in a register across the k-loop
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(l16));
+      const char* gt = uniform_ptr((const char*)xpl + (((size_t)(l_m0 >> 8) * nk + l_k) << 15) + unit * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gt + l16),
+                                       (__attribute__((address_space(3))) void*)(base + unit * 1024), 16, 0, 0);
+    } else {
     const half_t* pl = isw ? wpl : xpl;
     const int r0 = (isw ? l_n0 : l_m0) + q * 64 + h * 32;
     const char* gb = uniform_ptr((const char*)(pl + (size_t)r0 * a.K + k0));
     asm volatile("" : "+v"(poff));
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + poff),
                                      (__attribute__((address_space(3))) void*)(base + (isw ? XBYTES : 0) + unit * 1024), 16, 0, 0);
+    }
     if (KIND == 0 && p == 0) {
       unsigned l4;
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 2, %0" : "=v"(l4));
@@ -407,6 +420,17 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
       [[maybe_unused]] const gelu_coef_t gk = gelu_coefficients();
       // one specialised copy of the loop per lo format of the tile (compile-time LOFMT: -1 = no lo plane), picked by a
       // wave-uniform branch per tile instead of a format test per element group
+      // TILED output (FC1 -> FC2): element offset = tile base (wave-uniform: row block tm, 64-column chunk of this wave, the
+      // wave's 128-row half) + j·16 rows + this lane's (row, swizzled 16-byte chunk).  Rows rd_row and rd_row + 8 of a
+      // 16-row group differ in bit 2 of the swizzle term ((row >> 1) & 7), i.e. in 32 halves of the chunk offset.
+      constexpr bool TILED_OUT = (EPI == ZK_EPI_GELU) && TILED;
+      [[maybe_unused]] size_t tl_base = 0;
+      [[maybe_unused]] unsigned tl_off[2] = {0, 0};
+      if constexpr (TILED_OUT) {
+        tl_base = (((size_t)tm * (a.N >> 6) + (n0 >> 6)) * 256 + wm * TM) * 64;
+        tl_off[0] = (unsigned)(rd_row * 64 + ((rd_ch ^ (rd_row >> 1)) << 3));
+        tl_off[1] = (tl_off[0] ^ 32u) + 8 * 64;
+      }
       auto store_tile = [&](auto fmt_c) __attribute__((always_inline)) {
         constexpr int LOFMT = decltype(fmt_c)::value;
 #pragma unroll
@@ -435,12 +459,14 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
           for (int t = 0; t < 2; ++t) {
             const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
             const int m = m0 + j * 16 + rd_row + 8 * t;
+            // this lane's 8 halves in a plane: row-major, or the tile form (uniform tile base + 32-bit lane offset: see tl_off)
+            const size_t oo = TILED_OUT ? tl_base + (size_t)(tl_off[t] + j * 1024) : (size_t)m * a.N + n0 + rd_ch * 8;
             // (non-temporal: the planes are read by the NEXT kernel from their first row on, long after these lines would have
             // left the caches; kept out of L2 they stop evicting the W / X lines of the k-loops: FC1 +2 %, QKV +0.7 %)
 #ifdef ZK_C8_NO_NT      // probe builds: plain stores
-            if (m < a.M) *(h8_t*)(a.o_hi + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+            if (m < a.M) *(h8_t*)(a.o_hi + oo) = v;
 #else
-            if (m < a.M) __builtin_nontemporal_store(v, (h8_t*)(a.o_hi + (size_t)m * a.N + n0 + rd_ch * 8));
+            if (m < a.M) __builtin_nontemporal_store(v, (h8_t*)(a.o_hi + oo));
 #endif
           }
           if constexpr (LOFMT >= 0) {
@@ -450,10 +476,11 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
             for (int t = 0; t < 2; ++t) {
               const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
               const int m = m0 + j * 16 + rd_row + 8 * t;
+              const size_t oo = TILED_OUT ? tl_base + (size_t)(tl_off[t] + j * 1024) : (size_t)m * a.N + n0 + rd_ch * 8;
 #ifdef ZK_C8_NO_NT
-              if (m < a.M) *(h8_t*)(a.o_lo + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+              if (m < a.M) *(h8_t*)(a.o_lo + oo) = v;
 #else
-              if (m < a.M) __builtin_nontemporal_store(v, (h8_t*)(a.o_lo + (size_t)m * a.N + n0 + rd_ch * 8));
+              if (m < a.M) __builtin_nontemporal_store(v, (h8_t*)(a.o_lo + oo));
 #endif
             }
           }
@@ -624,10 +651,10 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 #endif
 }
 
-template <int EPI>
+template <int EPI, bool TILED = false>
 void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144 + 8 * 512;
-  auto k = gemm_c8_kernel<EPI>;
+  auto k = gemm_c8_kernel<EPI, TILED>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   const int ntiles = ((a.M + 255) / 256) * (a.N / 256);
@@ -641,8 +668,8 @@ void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
 void zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s) {
   switch (epi) {
     case ZK_EPI_STORE: launch_cfg<ZK_EPI_STORE>(a, s); break;
-    case ZK_EPI_GELU: launch_cfg<ZK_EPI_GELU>(a, s); break;
-    case ZK_EPI_RESID: launch_cfg<ZK_EPI_RESID>(a, s); break;
+    case ZK_EPI_GELU: if (a.tiled) launch_cfg<ZK_EPI_GELU, true>(a, s); else launch_cfg<ZK_EPI_GELU>(a, s); break;
+    case ZK_EPI_RESID: if (a.tiled) launch_cfg<ZK_EPI_RESID, true>(a, s); else launch_cfg<ZK_EPI_RESID>(a, s); break;
     default: launch_cfg<ZK_EPI_PATCH>(a, s); break;
   }
 }

@@ -126,6 +126,8 @@ struct zk_gemm_args {
   int lo_c8_to = 1 << 30;   //   QKV: the fp8-corrected QK^T), the others an fp16 lo plane (q: re-split by attention; v: the Vl·P pass)
   int w_exp;           // ZK_F16C8: the weight's c8 plane holds (fp8(W·2^w_exp), fp8((W-Wh)·2^(w_exp+11)))
   int rev = 0;         // ZK_F16C8: walk the row blocks from the last to the first (same results, other order)
+  int tiled = 0;       // ZK_F16C8, the FC1 -> FC2 hand-off: GELU writes / RESID reads its activation planes as k-slice-major tiles
+                       // (gemm_c8.hip, TILED); planes must hold whole 256-row blocks.  Other epilogues ignore it
 };
 
 // launchers (each file owns its kernels)
