@@ -104,13 +104,14 @@ typedef int i4v_t __attribute__((ext_vector_type(4)));
 typedef int i8v_t __attribute__((ext_vector_type(8)));
 struct frag_t { i4v_t a, b; };
 
-// TILED (zk_gemm_args::tiled): the operand handed from FC1 to FC2 lies in k-slice-major tiles — [row block][64-k chunk][256
-// rows][128 B], the 128 bytes of a row already in the LDS image's swizzled chunk order — so that the X half of a ring step is
-// 32 KiB CONTIGUOUS in HBM (one DRAM page run instead of 256 row segments 6 KiB apart) and an LDS-DMA piece is a linear
-// kilobyte.  EPI_GELU + TILED: the epilogue writes its planes that way; EPI_RESID + TILED: the loader reads X that way.
-template <int EPI, bool TILED>
+// XT / OT (zk_gemm_args::x_tiled / o_tiled, zk_planes::tiled): activation planes in k-slice-major tiles — [row block][64-k
+// chunk][256 rows][128 B], the 128 bytes of a row already in the LDS image's swizzled chunk order — so that the X half of a
+// ring step is 32 KiB CONTIGUOUS in HBM (one DRAM page run instead of 256 row segments 1.5-6 KiB apart) and an LDS-DMA piece
+// is a linear kilobyte.  XT: the loader reads X that way; OT (GELU epilogue): the output planes are written that way.
+template <int EPI, bool XT, bool OT>
 __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
-  static_assert(!TILED || ZK_C8_ROLES, "the tiled operand form is read by the role loader only");
+  static_assert(!XT || ZK_C8_ROLES, "the tiled operand form is read by the role loader only");
+  static_assert(!OT || EPI == ZK_EPI_GELU, "only the GELU epilogue writes tiled planes");
   constexpr int BM = 256, BN = 256, BK = 64, WM = 2, WN = 4;
   constexpr int ROWB = 128, CPR = 8, RPI = 8;
   constexpr int TM = BM / WM, TN = BN / WN;       // 128 x 64 per wave
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
     const int k0 = l_k * BK;
     const int q = (p >> 1) & 3, h = p & 1, unit = q * 8 + (wave & 3) + 4 * h;
     const bool isw = p >= 8;
-    if (EPI == ZK_EPI_RESID && TILED && !isw) {      // (p is a constant at every call site: no branch is emitted)
+    if (XT && !isw) {      // (p is a constant at every call site: no branch is emitted)
       unsigned l16;      // lane·16, read here instead of kept in a register across the k-loop
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(l16));
       const char* gt = uniform_ptr((const char*)xpl + (((size_t)(l_m0 >> 8) * nk + l_k) << 15) + unit * 1024);
@@ -420,10 +421,10 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
       [[maybe_unused]] const gelu_coef_t gk = gelu_coefficients();
       // one specialised copy of the loop per lo format of the tile (compile-time LOFMT: -1 = no lo plane), picked by a
       // wave-uniform branch per tile instead of a format test per element group
-      // TILED output (FC1 -> FC2): element offset = tile base (wave-uniform: row block tm, 64-column chunk of this wave, the
+      // tiled output (OT): element offset = tile base (wave-uniform: row block tm, 64-column chunk of this wave, the
       // wave's 128-row half) + j·16 rows + this lane's (row, swizzled 16-byte chunk).  Rows rd_row and rd_row + 8 of a
       // 16-row group differ in bit 2 of the swizzle term ((row >> 1) & 7), i.e. in 32 halves of the chunk offset.
-      constexpr bool TILED_OUT = (EPI == ZK_EPI_GELU) && TILED;
+      constexpr bool TILED_OUT = OT;
       [[maybe_unused]] size_t tl_base = 0;
       [[maybe_unused]] unsigned tl_off[2] = {0, 0};
       if constexpr (TILED_OUT) {
@@ -651,10 +652,10 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 #endif
 }
 
-template <int EPI, bool TILED = false>
+template <int EPI, bool XT = false, bool OT = false>
 void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * (256 + 256) * 128 + 2 * 8 * 256 + 8 * 16 * 144 + 8 * 512;
-  auto k = gemm_c8_kernel<EPI, TILED>;
+  auto k = gemm_c8_kernel<EPI, XT, OT>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   const int ntiles = ((a.M + 255) / 256) * (a.N / 256);
@@ -667,9 +668,14 @@ void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
 // Host-side shape contract as zk_launch_gemm: N % 256 == 0, K % 64 == 0, M >= 1; x_lo / w_lo are c8 planes.
 void zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s) {
   switch (epi) {
-    case ZK_EPI_STORE: launch_cfg<ZK_EPI_STORE>(a, s); break;
-    case ZK_EPI_GELU: if (a.tiled) launch_cfg<ZK_EPI_GELU, true>(a, s); else launch_cfg<ZK_EPI_GELU>(a, s); break;
-    case ZK_EPI_RESID: if (a.tiled) launch_cfg<ZK_EPI_RESID, true>(a, s); else launch_cfg<ZK_EPI_RESID>(a, s); break;
+    case ZK_EPI_STORE: if (a.x_tiled) launch_cfg<ZK_EPI_STORE, true>(a, s); else launch_cfg<ZK_EPI_STORE>(a, s); break;
+    case ZK_EPI_GELU:
+      if (a.x_tiled && a.o_tiled) launch_cfg<ZK_EPI_GELU, true, true>(a, s);
+      else if (a.o_tiled) launch_cfg<ZK_EPI_GELU, false, true>(a, s);
+      else if (a.x_tiled) launch_cfg<ZK_EPI_GELU, true, false>(a, s);
+      else launch_cfg<ZK_EPI_GELU>(a, s);
+      break;
+    case ZK_EPI_RESID: if (a.x_tiled) launch_cfg<ZK_EPI_RESID, true>(a, s); else launch_cfg<ZK_EPI_RESID>(a, s); break;
     default: launch_cfg<ZK_EPI_PATCH>(a, s); break;
   }
 }

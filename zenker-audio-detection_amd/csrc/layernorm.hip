@@ -12,12 +12,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t row_stride,
+#ifndef ZK_LN_WAVES
+#define ZK_LN_WAVES 4      // rows (= waves) per workgroup
+#endif
+__global__ __launch_bounds__(64 * ZK_LN_WAVES) void layernorm_kernel(const float* __restrict__ x, int64_t row_stride,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int rows, half_t* o_hi,
-                                                        half_t* o_lo, int lo_fmt, int32_t* rowexp, float eps, int rev) {
+                                                        half_t* o_lo, int lo_fmt, int32_t* rowexp, float eps, int rev, int tiled) {
   const int lane = threadIdx.x & 63;
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = blockIdx.x * ZK_LN_WAVES + (threadIdx.x >> 6);
   if (row >= rows) return;
   if (rev) row = rows - 1 - row;
   const float* xr = x + (size_t)row * row_stride;
@@ -70,8 +73,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       zk_pin(y[j]);
       hi[j] = (half_t)y[j];
     }
-    *(h4_t*)(o_hi + (size_t)row * ZK_HIDDEN + c) = hi;
-    if (o_lo) *(h4_t*)(o_lo + (size_t)row * ZK_HIDDEN + c) = zk_lo4(y, hi, lo_fmt);
+    // (tiled planes, zk_planes::tiled: the wave's 512 contiguous bytes become four whole 128-byte lines, one per 64-column chunk)
+    const size_t oo = tiled ? zk_tiled_off(row, c, ZK_HIDDEN) : (size_t)row * ZK_HIDDEN + c;
+    *(h4_t*)(o_hi + oo) = hi;
+    if (o_lo) *(h4_t*)(o_lo + oo) = zk_lo4(y, hi, lo_fmt);
   }
 }
 
@@ -80,6 +85,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 void zk_launch_layernorm(const float* x, int64_t row_stride, const float* gamma, const float* beta, int rows,
                          zk_planes out, float eps, hipStream_t s, int rev) {
   if (rows <= 0) return;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, gamma, beta, rows,
-                     out.hi, out.lo, out.lo_fmt, (out.lo && out.lo_fmt == ZK_LO_C8) ? out.rowexp : nullptr, eps, rev);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + ZK_LN_WAVES - 1) / ZK_LN_WAVES), dim3(64 * ZK_LN_WAVES), 0, s, x, row_stride, gamma, beta, rows,
+                     out.hi, out.lo, out.lo_fmt, (out.lo && out.lo_fmt == ZK_LO_C8) ? out.rowexp : nullptr, eps, rev, out.tiled);
 }

@@ -49,7 +49,17 @@ struct zk_planes {
   // saturates at 448 and small rows keep their correction) and the consuming GEMM multiplies its accumulator row by
   // 2^s_m in the epilogue — exact, and free in the k-loop.  nullptr: planes are unscaled.
   int32_t* rowexp;
+  // ZK_F16C8 GEMM operands only: the planes lie in k-slice-major tiles — [row block of 256][64-column chunk][256 rows][128 B],
+  // the eight 16-byte chunks of a row in the LDS image's swizzled order (chunk c of row m at position c ^ ((m >> 1) & 7)) —
+  // so that the X half of a GEMM ring step is 32 KiB contiguous in HBM (gemm_c8.hip).  Planes must hold whole row blocks.
+  int tiled = 0;
 };
+#ifdef __HIPCC__
+// element offset of columns [c, c + 8) ∩ one 16-byte chunk of row m in a tiled plane with K columns
+__device__ __forceinline__ size_t zk_tiled_off(int m, int c, int K) {
+  return (((size_t)(m >> 8) * (K >> 6) + (c >> 6)) * 256 + (m & 255)) * 64 + (((((c & 63) >> 3) ^ ((m >> 1) & 7))) << 3) + (c & 7);
+}
+#endif
 
 #define ZK_C8_SHIFT 11   // (x - hi) is scaled by 2^11 before the fp8 rounding: |x - hi| <= 2^-11 |x|
 
@@ -126,8 +136,8 @@ struct zk_gemm_args {
   int lo_c8_to = 1 << 30;   //   QKV: the fp8-corrected QK^T), the others an fp16 lo plane (q: re-split by attention; v: the Vl·P pass)
   int w_exp;           // ZK_F16C8: the weight's c8 plane holds (fp8(W·2^w_exp), fp8((W-Wh)·2^(w_exp+11)))
   int rev = 0;         // ZK_F16C8: walk the row blocks from the last to the first (same results, other order)
-  int tiled = 0;       // ZK_F16C8, the FC1 -> FC2 hand-off: GELU writes / RESID reads its activation planes as k-slice-major tiles
-                       // (gemm_c8.hip, TILED); planes must hold whole 256-row blocks.  Other epilogues ignore it
+  int x_tiled = 0;     // ZK_F16C8: the x planes are k-slice-major tiles (zk_planes::tiled)
+  int o_tiled = 0;     // ZK_F16C8, GELU epilogue: write the output planes that way (the operand of the next GEMM)
 };
 
 // launchers (each file owns its kernels)

@@ -387,7 +387,7 @@ int next_dir(zk_ctx* c) {
 
 void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, int M, int N, int K, int epi, int nsplit,
               zk_planes out, float* resid, const float* pos, int lo_n_limit, int lo_c8_from = 1 << 30, int rev = 0,
-              int lo_c8_to = 1 << 30, int tiled = 0) {
+              int lo_c8_to = 1 << 30) {
   ProfScope ps(c, cls);
   if (c->prof) c->prof_flops[cls] += 2.0 * M * (double)N * K;
   zk_gemm_args a;
@@ -397,13 +397,17 @@ void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias,
   a.o_hi = out.hi; a.o_lo = (nsplit != ZK_F16) ? out.lo : nullptr;
   a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.lo_c8_from = lo_c8_from; a.lo_c8_to = lo_c8_to; a.w_exp = w.exp;
   a.rev = rev;
-  a.tiled = (nsplit == ZK_F16C8) ? tiled : 0;
+  a.x_tiled = (nsplit == ZK_F16C8) ? x.tiled : 0;
+  a.o_tiled = (nsplit == ZK_F16C8 && epi == ZK_EPI_GELU) ? out.tiled : 0;
   if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
   else zk_launch_gemm(a, epi, nsplit, c->stream);
 }
 
 #ifndef ZK_MID_TILED
 #define ZK_MID_TILED 1      // 0: row-major GELU planes between FC1 and FC2 (A/B switch)
+#endif
+#ifndef ZK_XN_TILED
+#define ZK_XN_TILED 1       // 0: row-major LayerNorm planes in front of QKV / FC1 (A/B switch)
 #endif
 // forward of nb windows (one micro-batch) whose patch matrix is already in c->patchA
 int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
@@ -415,6 +419,9 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
   float* hidden = c->hidden.as<float>();
   zk_planes pa = c->patchA.get(sp, lf), xn = c->xn.get(sp, lf), qkv = c->qkv.get(sp), att = c->att.get(sp, lf),
             mid = c->mid.get(sp, lf);
+  // ZK_F16C8: the big GEMM operands that a GEMM-side kernel both writes and reads go as k-slice-major tiles
+  // (zk_planes::tiled; the workspace planes hold whole 256-row blocks): LayerNorm -> QKV / FC1, FC1 -> FC2
+  if (ns == ZK_F16C8) { xn.tiled = ZK_XN_TILED; mid.tiled = ZK_MID_TILED; }
   {
     ProfScope ps(c, P_EMBED);
     zk_launch_cls_rows(hidden, sm.cls, sm.dist, sm.pos, nb, c->stream);
@@ -462,12 +469,10 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
     run_gemm(c, P_GEMM_O, att, L.wo, L.bo, M, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
              zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c));
     { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln2_g, L.ln2_b, M, xn, sm.eps, c->stream, next_dir(c)); }
-    // (ZK_F16C8: the GELU planes go from FC1 to FC2 as k-slice-major tiles — zk_gemm_args::tiled; the workspace planes hold
-    // whole 256-row blocks)
     run_gemm(c, P_GEMM_FC1, xn, L.w1, L.b1, M, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid, nullptr, nullptr,
-             ZK_INTER, 1 << 30, next_dir(c), 1 << 30, ZK_MID_TILED);
+             ZK_INTER, 1 << 30, next_dir(c));
     run_gemm(c, P_GEMM_FC2, mid, L.w2, L.b2, M, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
-             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c), 1 << 30, ZK_MID_TILED);
+             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c));
     if (c->tap_layer == l) {
       HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
       HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
