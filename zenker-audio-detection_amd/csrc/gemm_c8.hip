@@ -82,6 +82,10 @@ constexpr int c8r_cnt(int c) {
   constexpr int T[8] = {16, 0, 0, 0, 0, 0, 0, 0};
 #elif ZK_C8_ROLES == 4
   constexpr int T[8] = {8, 8, 0, 0, 0, 0, 0, 0};
+#elif ZK_C8_ROLES == 6
+  constexpr int T[8] = {6, 6, 4, 0, 0, 0, 0, 0};
+#elif ZK_C8_ROLES == 7
+  constexpr int T[8] = {4, 4, 4, 2, 2, 0, 0, 0};
 #else
   constexpr int T[8] = {4, 3, 3, 2, 2, 2, 0, 0};
 #endif
