@@ -73,7 +73,8 @@ constexpr int TILE_B = KT * 128;        // bytes of one [64][64] fp16 image
 template <int NSPLIT>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __restrict__ qkv_hi,
                                                         const half_t* __restrict__ qkv_lo, half_t* __restrict__ o_hi,
-                                                        half_t* __restrict__ o_lo, int n_windows, int q_tiles, int lo_fmt, int row_limit, int rev) {
+                                                        half_t* __restrict__ o_lo, int n_windows, int q_tiles, int lo_fmt, int row_limit, int rev,
+                                                        int o_tiled) {
   constexpr bool SPLIT = (NSPLIT >= 2);
   constexpr bool C8 = (NSPLIT == 2);
   // LDS images of one 64-key tile: K: Kh, [Kl | Kc8]; V: Vh, [Vl].  Vl = fp16(v - fp16(v)), the lo plane the QKV epilogue
@@ -727,7 +728,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
 #ifdef ZK_ATT_NT
       if (row_base + r < S_) __builtin_nontemporal_store(v, (h8_t*)(plane + orow0 + (size_t)r * ZK_HIDDEN + rd_ch * 8));
 #else
-      if (row_base + r < S_) *(h8_t*)(plane + orow0 + (size_t)r * ZK_HIDDEN + rd_ch * 8) = v;
+      // (o_tiled: the output planes are the O projection's X operand in k-slice-major tiles, zk_planes::tiled — the head's 64
+      // columns are one chunk, eight consecutive rows of it 1 KiB contiguous)
+      const size_t oo = o_tiled ? zk_tiled_off((int)(tok0 + row_base + r), head * ZK_HEAD_DIM + rd_ch * 8, ZK_HIDDEN)
+                                : orow0 + (size_t)r * ZK_HIDDEN + rd_ch * 8;
+      if (row_base + r < S_) *(h8_t*)(plane + oo) = v;
 #endif
     }
   };
@@ -790,7 +795,7 @@ void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit
 #else
     const int pgrid = grid;
 #endif
-    hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(64 * NW), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, wg_tiles, out.lo_fmt, row_limit, rev);
+    hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(64 * NW), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, wg_tiles, out.lo_fmt, row_limit, rev, out.tiled);
   };
 #ifdef ZK_ATT_NO_VL
   constexpr int NIMG_SPLIT = 3;

@@ -69,15 +69,17 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ hidde
 __global__ __launch_bounds__(256) void gather_tok01_kernel(const half_t* __restrict__ a_hi, const half_t* __restrict__ a_lo,
                                                            const float* __restrict__ hidden, int n_windows,
                                                            half_t* __restrict__ o_hi, half_t* __restrict__ o_lo,
-                                                           float* __restrict__ h_out) {
+                                                           float* __restrict__ h_out, int a_tiled) {
   const int gid = blockIdx.x * 256 + threadIdx.x;       // one thread = 4 channels of one row
   if (gid >= n_windows * 2 * (ZK_HIDDEN / 4)) return;
   const int c4 = gid % (ZK_HIDDEN / 4);
   const int r = gid / (ZK_HIDDEN / 4);                   // b*2 + tok
   const size_t src = ((size_t)(r >> 1) * ZK_SEQ + (r & 1)) * ZK_HIDDEN + c4 * 4;
   const size_t dst = (size_t)r * ZK_HIDDEN + c4 * 4;
-  *(h4_t*)(o_hi + dst) = *(const h4_t*)(a_hi + src);
-  if (o_lo) *(h4_t*)(o_lo + dst) = *(const h4_t*)(a_lo + src);
+  // (the attention planes may lie in k-slice-major tiles, zk_planes::tiled; the compact output is row-major)
+  const size_t asrc = a_tiled ? zk_tiled_off((r >> 1) * ZK_SEQ + (r & 1), c4 * 4, ZK_HIDDEN) : src;
+  *(h4_t*)(o_hi + dst) = *(const h4_t*)(a_hi + asrc);
+  if (o_lo) *(h4_t*)(o_lo + dst) = *(const h4_t*)(a_lo + asrc);
   *(f4_t*)(h_out + dst) = *(const f4_t*)(hidden + src);
 }
 
@@ -88,7 +90,7 @@ void zk_launch_gather_tok01(zk_planes att, const float* hidden, int n_windows, z
   if (n_windows <= 0) return;
   const int total = n_windows * 2 * (ZK_HIDDEN / 4);
   hipLaunchKernelGGL(gather_tok01_kernel, dim3((total + 255) / 256), dim3(256), 0, s, att.hi, att.lo, hidden, n_windows,
-                     att_out.hi, att_out.lo, hidden_out);
+                     att_out.hi, att_out.lo, hidden_out, att.tiled);
 }
 
 void zk_launch_im2col_compact(const float* feats, int n_frames, const int32_t* win_idx, int n_windows, float mean,

@@ -406,6 +406,9 @@ void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias,
 #ifndef ZK_MID_TILED
 #define ZK_MID_TILED 1      // 0: row-major GELU planes between FC1 and FC2 (A/B switch)
 #endif
+#ifndef ZK_ATT_TILED
+#define ZK_ATT_TILED 1      // 0: row-major attention output planes in front of the O projection (A/B switch)
+#endif
 #ifndef ZK_XN_TILED
 #define ZK_XN_TILED 1       // 0: row-major LayerNorm planes in front of QKV / FC1 (A/B switch)
 #endif
@@ -420,8 +423,8 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
   zk_planes pa = c->patchA.get(sp, lf), xn = c->xn.get(sp, lf), qkv = c->qkv.get(sp), att = c->att.get(sp, lf),
             mid = c->mid.get(sp, lf);
   // ZK_F16C8: the big GEMM operands that a GEMM-side kernel both writes and reads go as k-slice-major tiles
-  // (zk_planes::tiled; the workspace planes hold whole 256-row blocks): LayerNorm -> QKV / FC1, FC1 -> FC2
-  if (ns == ZK_F16C8) { xn.tiled = ZK_XN_TILED; mid.tiled = ZK_MID_TILED; }
+  // (zk_planes::tiled; the workspace planes hold whole 256-row blocks): LayerNorm -> QKV / FC1, FC1 -> FC2, attention -> O
+  if (ns == ZK_F16C8) { xn.tiled = ZK_XN_TILED; mid.tiled = ZK_MID_TILED; att.tiled = ZK_ATT_TILED; }
   {
     ProfScope ps(c, P_EMBED);
     zk_launch_cls_rows(hidden, sm.cls, sm.dist, sm.pos, nb, c->stream);
