@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_WINDOW_STAGE = 261.03e9          # dense AST forward at S=1214
 PEAK_F16_DENSE = 2.5e15                   # MI355X_MICROARCH.md: BF16/FP16 MFMA dense peak
-TRAFFIC_FILE = "r03f_pmc_traffic.json"     # rocprofv3 --pmc passes of this round (tools/pmc_traffic.py)
+TRAFFIC_FILE = "r03g_pmc_traffic.json"     # rocprofv3 --pmc passes of this round (tools/pmc_traffic.py)
 
 
 def main():
