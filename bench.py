@@ -28,9 +28,11 @@ import argparse
 import hashlib
 import json
 import os
+import signal
 import struct
 import sys
 import time
+import traceback
 
 import numpy as np
 
@@ -40,7 +42,38 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_WINDOW_STAGE = 261.03e9          # dense AST forward at S=1214
 PEAK_F16_DENSE = 2.5e15                   # MI355X_MICROARCH.md: BF16/FP16 MFMA dense peak
-TRAFFIC_FILE = "r03g_pmc_traffic.json"     # rocprofv3 --pmc passes of this round (tools/pmc_traffic.py)
+TRAFFIC_FILE = "r04_pmc_traffic.json"      # rocprofv3 --pmc passes of this round (tools/pmc_traffic.py)
+CLOCK_FILE = "r04_gemm_clock.json"         # in-kernel s_memtime / s_memrealtime pair of a stamp build (tools/gemm_stamps.py)
+# matrix-pipe passes per algorithmic FLOP of each compute mode: f16c8 = one fp16 pass + one fp8 pass of
+# K' = 2K bytes at twice the rate = 2 fp16-pass-equivalents; f16x3 = 3 fp16 passes.  Attention, per 64-key tile and wave:
+# a single pass is 16 x 32x32x16 MFMAs = 512 matrix-pipe cycles; f16c8 runs QK^T as 8 fp16 + 4 fp8 32x32x64 (512 cycles) and
+# P·V as Vh·P + Vl·P (16 fp16 MFMAs, 512 cycles): 1 024 cycles against 512
+PASSES_PER_FLOP = {"f16c8": 2.0, "f16x3": 3.0, "f16": 1.0}
+ATTN_PASSES_PER_FLOP = {"f16c8": 2.0, "f16x3": 2.5, "f16": 1.0}
+import argparse
+import hashlib
+import json
+import os
+import signal
+import struct
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "zenker-audio-detection_amd"))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_WINDOW_STAGE = 261.03e9          # dense AST forward at S=1214
+PEAK_F16_DENSE = 2.5e15                   # MI355X_MICROARCH.md: BF16/FP16 MFMA dense peak
+TRAFFIC_FILE = "r04_pmc_traffic.json"      # rocprofv3 --pmc passes of this round (tools/pmc_traffic.py)
+CLOCK_FILE = "r04_gemm_clock.json"         # in-kernel s_memtime / s_memrealtime pair of a stamp build (tools/gemm_stamps.py)
+# matrix-pipe passes per algorithmic FLOP of each compute mode: f16c8 = one fp16 pass + one fp8 pass of
+# K' = 2K bytes at twice the rate = 2 fp16-pass-equivalents; f16x3 = 3 fp16 passes; attention = QK^T 1.5 + PV 2.0 over 2
+PASSES_PER_FLOP = {"f16c8": 2.0, "f16x3": 3.0, "f16": 1.0}
+ATTN_PASSES_PER_FLOP = {"f16c8": 1.75, "f16x3": 2.5, "f16": 1.0}
 
 
 def main():
@@ -61,7 +94,10 @@ def main():
     ap.add_argument("--cpu-repeats", type=int, default=3, help="CPU-baseline repeats, median reported (SURVEY §8d: 3)")
     ap.add_argument("--cpu-budget-s", type=float, default=200.0,
                     help="the CPU leg stops repeating rather than exceed this (the line states the repeats that ran)")
+    ap.add_argument("--time-budget-s", type=float, default=270.0,
+                    help="auxiliary legs that would run past this many seconds since start are skipped (and say so)")
     args = ap.parse_args()
+    t_bench0 = time.perf_counter()
     if args.headline_only:
         args.no_fast = args.no_sweep = args.no_cpu = True
 
@@ -237,9 +273,16 @@ def main():
                   note="fp64 FFT in LDS: VALU / barrier-bound, not HBM-bound; 0.06 % of the step")
     executed = sum(prof[n][2] for n in ("gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention"))
     dom = max((k for k in roof_all if "tflops" in roof_all[k]), key=lambda k: roof_all[k]["share"])
+    passes = (ATTN_PASSES_PER_FLOP if dom == "attention" else PASSES_PER_FLOP)[args.mode]
+    frac = roof_all[dom]["tflops"] * 1e12 / PEAK_F16_DENSE
     roofline = {"kernel": dom, "bound": "mfma", "achieved": roof_all[dom]["tflops"], "peak": PEAK_F16_DENSE / 1e12,
-                "unit": "TFLOP/s", "frac": roof_all[dom]["tflops"] * 1e12 / PEAK_F16_DENSE, "traffic": None,
-                "ms_per_launch": roof_all[dom]["ms_per_launch"], "launches": roof_all[dom]["launches"]}
+                "unit": "TFLOP/s", "frac": frac, "traffic": None,
+                "ms_per_launch": roof_all[dom]["ms_per_launch"], "launches": roof_all[dom]["launches"],
+                # how to read `frac`: the parity mode spends `passes_per_flop` fp16-pass-equivalents of the matrix pipe on
+                # every algorithmic FLOP, so its ceiling is 1 / passes_per_flop of the dense peak; frac = (1 / passes) x
+                # (in-kernel clock / 2.4 GHz) x (k-loop share of the kernel) x (pipe occupancy inside the k-loop)
+                "passes_per_flop": passes, "mode_ceiling_frac": 1.0 / passes, "frac_of_mode_ceiling": frac * passes,
+                "in_kernel_clock_ghz": None, "mfma_util": None}
     # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; the value is the one measured
     # with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH correction applied) and committed
     # under profiles/ TOGETHER WITH the sha256 of the libzkast.so it was measured on: a file measured on another build
@@ -251,10 +294,17 @@ def main():
                "gemm_o": "gemm_o(resid)", "attention": "attention"}[dom]
         if tr.get("libzkast_sha256") == so_hash and args.mode == "f16c8":
             roofline["traffic"] = tr["kernels"][key]["hbm_bytes_per_launch_corrected"]
+            roofline["mfma_util"] = tr["kernels"][key].get("mfma_util")      # SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES)
             roofline["traffic_source"] = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc, separate passes, same libzkast.so)"
         else:
             roofline["traffic_source"] = f"profiles/{TRAFFIC_FILE} was measured on another build of libzkast.so: not used"
-    except Exception:
+    except Exception as e:      # noqa: BLE001
+        roofline["traffic_source"] = f"profiles/{TRAFFIC_FILE}: {type(e).__name__}"
+    try:      # clock the chip held inside the dominant kernel: s_memtime against the 100 MHz s_memrealtime of a stamp build
+        ck = json.load(open(os.path.join(ROOT, "profiles", CLOCK_FILE)))
+        roofline["in_kernel_clock_ghz"] = ck["kernels"][dom]["ghz"]
+        roofline["clock_source"] = f"profiles/{CLOCK_FILE} ({ck.get('note', 'tools/gemm_stamps.py')})"
+    except Exception:      # noqa: BLE001
         pass
     e2e_flops = value / world * (1.0 + K / B) * FLOP_PER_WINDOW_STAGE
     out = {
@@ -279,38 +329,42 @@ def main():
     }
 
     # ---- gate-rate sweep (g in {0.1, 0.5, 1.0}); windows/s counts stage-1 windows, as the headline ----
-    if not args.no_sweep:
+    def gate_sweep():
         sweep = {f"{K / B:.2f}": {"value": value, "unit": "windows/s", "stage2_windows": K}}
         nsw = max(1, args.steps // 2)
-        for g in (0.5, 0.1):
-            state["thr"], _k = thr_for(g)
-            dts, _ = timed(nsw, 1)
-            kk = int(sw_cnt[0])
-            sweep[f"{kk / B:.2f}"] = {"value": world * B * nsw / dts, "unit": "windows/s", "stage2_windows": kk,
-                                      "thr1": state["thr"]}
-        state["thr"] = thr_for(args.gate_rate)[0]
+        try:
+            for g in (0.5, 0.1):
+                state["thr"], _k = thr_for(g)
+                dts, _ = timed(nsw, 1)
+                kk = int(sw_cnt[0])
+                sweep[f"{kk / B:.2f}"] = {"value": world * B * nsw / dts, "unit": "windows/s", "stage2_windows": kk,
+                                          "thr1": state["thr"]}
+        finally:
+            state["thr"] = thr_for(args.gate_rate)[0]
         out["gate_sweep"] = sweep
 
     # ---- secondary: the 3-pass mode (same tolerance) and single-pass fp16 (fails the 1e-3 tolerance), each with its
     #      measured stage-1 logit difference to the headline mode ----
-    if not args.no_fast and args.mode == "f16c8":
+    def other_modes():
         step()
         barrier()
         ref1 = s1_logits.copy()
         nsec = max(1, args.steps // 2)
-        for key, mode, note in (("x3_mode", "f16x3", "(hi,lo) fp16 pairs, 3 MFMA passes; also meets the 1e-3 logit tolerance"),
-                                ("fast_mode", "f16", "single fp16 MFMA pass; exceeds the 1e-3 logit tolerance, not the headline")):
-            m1.set_compute_mode(mode)
-            m2.set_compute_mode(mode)
-            dtf, _ = timed(nsec, 1)
-            err = float(np.abs(s1_logits - ref1).max())
-            out[key] = {"dtype": mode, "value": world * B * nsec / dtf, "unit": "windows/s",
-                        "stage1_logit_max_abs_diff_vs_f16c8": err, "note": note}
-        m1.set_compute_mode(args.mode)
-        m2.set_compute_mode(args.mode)
+        try:
+            for key, mode, note in (("x3_mode", "f16x3", "(hi,lo) fp16 pairs, 3 MFMA passes; also meets the 1e-3 logit tolerance"),
+                                    ("fast_mode", "f16", "single fp16 MFMA pass; exceeds the 1e-3 logit tolerance, not the headline")):
+                m1.set_compute_mode(mode)
+                m2.set_compute_mode(mode)
+                dtf, _ = timed(nsec, 1)
+                err = float(np.abs(s1_logits - ref1).max())
+                out[key] = {"dtype": mode, "value": world * B * nsec / dtf, "unit": "windows/s",
+                            "stage1_logit_max_abs_diff_vs_f16c8": err, "note": note}
+        finally:
+            m1.set_compute_mode(args.mode)
+            m2.set_compute_mode(args.mode)
 
     # ---- BASELINE.json configs[1] as an extra line: batch 256, stage-1 only (log-mel + forward), all modes ----
-    if rank == 0 and world == 1 and not args.headline_only:
+    def config1():
         def stage1_b256(reps=3):
             n256 = min(256, B)
             ctx.logmel(audio, n_samples, 0, hop, win, n256); ctx.ast_forward(0, None, None, n256, s1_logits[:n256])
@@ -321,38 +375,85 @@ def main():
             barrier()
             return n256 * reps / (time.perf_counter() - t0)
         cfg1 = {"workload": "configs[1]: batch=256 windows, stage-1 only (log-mel + AST forward)", "unit": "windows/s"}
-        for md in ("f16c8", "f16x3", "f16"):
-            m1.set_compute_mode(md); cfg1[md] = stage1_b256()
-        m1.set_compute_mode(args.mode)
+        try:
+            for md in ("f16c8", "f16x3", "f16"):
+                m1.set_compute_mode(md); cfg1[md] = stage1_b256()
+        finally:
+            m1.set_compute_mode(args.mode)
         out["config1_stage1_b256"] = cfg1
 
-    # ---- resample line (HBM GB/s of the 48 -> 16 kHz polyphase kernel, reported separately) ----
-    if rank == 0 and world == 1 and not args.headline_only:
-        n48 = 48000 * 60 * 30                                  # configs[3]'s 30 min at 48 kHz, device-resident fp32
-        a48 = torch.randn(n48, device=dev) * 0.1              # (torch only lends the two device buffers of this auxiliary line)
-        o16 = torch.empty((n48 + 2) // 3, dtype=torch.float32, device=dev)
-        ctx.resample_into(a48, n48, 48000, 16000, o16)
-        barrier(); t0 = time.perf_counter()
-        for _ in range(5):
-            ctx.resample_into(a48, n48, 48000, 16000, o16)
-        barrier()
-        rs = (time.perf_counter() - t0) / 5
-        rs_bytes = 4 * (n48 + o16.numel())
-        out["resample_48k_to_16k"] = {"ms_per_launch": rs * 1e3, "algorithmic_bytes_per_launch": rs_bytes,
-                                      "gb_per_s": rs_bytes / rs / 1e9, "frac_of_hbm_peak": rs_bytes / rs / 8.0e12,
-                                      "sample": "30 min of 48 kHz fp32 audio resident in HBM, host-timed over 5 launches"}
-        del a48, o16
+    # ---- load_audio line (HBM GB/s of the 48 -> 16 kHz polyphase kernel, reported separately): the product's
+    #      own zk_audio_load on configs[3]'s recording (30 min of 48 kHz mono PCM16, 172.8 MB of sample bytes in host
+    #      memory): one upload, decode + channel mean and the resampler on the device, kernels timed by the library's HIP
+    #      events on the context's stream; no torch buffer takes part ----
+    def resample_leg():
+        n48 = 48000 * 60 * 30
+        pcm = (np.random.default_rng(5).standard_normal(n48).astype(np.float32) * 3000).astype("<i2")
+        raw = pcm.tobytes()
+        try:
+            n16 = ctx.audio_load(raw, 1, 16, 1, 48000, 16000)      # first call sizes the buffers
+            ctx.prof_begin()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ctx.audio_load(raw, 1, 16, 1, 48000, 16000)
+            wall = (time.perf_counter() - t0) / 3
+            pr = ctx.prof_end()
+        finally:      # the timed region's recording goes back into the audio slot
+            assert ctx.audio_load(rec.tobytes(), 3, 32, 1, 16000, 16000) == n_samples
+        rs_ms, rs_n, _ = pr["resample"]
+        dc_ms, dc_n, _ = pr["wav_decode"]
+        rs, dc = rs_ms / rs_n * 1e-3, dc_ms / dc_n * 1e-3
+        rs_bytes, dc_bytes = 4 * (n48 + n16), 2 * n48 + 4 * n48
+        out["resample_48k_to_16k"] = {
+            "ms_per_launch": rs * 1e3, "algorithmic_bytes_per_launch": rs_bytes, "gb_per_s": rs_bytes / rs / 1e9,
+            "frac_of_hbm_peak": rs_bytes / rs / 8.0e12,
+            "wav_decode": {"ms_per_launch": dc * 1e3, "algorithmic_bytes_per_launch": dc_bytes, "gb_per_s": dc_bytes / dc / 1e9,
+                           "frac_of_hbm_peak": dc_bytes / dc / 8.0e12},
+            "load_audio_wall_ms_pcie_inclusive": wall * 1e3,
+            "sample": "zk_audio_load of 30 min of 48 kHz mono PCM16 (172.8 MB from pageable host memory): upload + decode + "
+                      "resample; kernels timed with HIP events on the context's stream, 3 loads"}
+
+    # ---- parity inside the bench, on the INPUT-SENSITIVE weight set ("sens": logits span > 6 over the golden windows, the
+    #      set that exposed round 3's 1.17e-3 hole) rather than on the headline's "wide" set: GPU half here, the checker's
+    #      half comes out of the CPU leg below (its stage weights are these; timing does not depend on the values) ----
+    n_cpu = args.cpu_windows
+    sens1, sens2 = synth.make_ast_weights(31, "sens"), synth.make_ast_weights(33, "sens")
+    gpu_sens = {}
+
+    def parity_gpu():
+        try:
+            for st, sd, fxs in ((0, sens1, S1), (1, sens2, S2)):
+                ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd, stage=st, compute_mode=args.mode,
+                                            device=local_rank, fx_mean=fxs[0], fx_std=fxs[1])
+            ctx.logmel(audio, n_samples, 0, hop, win, n_cpu)
+            for st in (0, 1):
+                lg = np.empty((n_cpu, 2), np.float32)
+                ctx.ast_forward(st, None, None, n_cpu, lg)
+                gpu_sens[st] = lg
+        finally:      # the headline's weights go back (later legs and a re-run see the timed configuration)
+            ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd1s, stage=0, compute_mode=args.mode,
+                                        device=local_rank, fx_mean=S1[0], fx_std=S1[1])
+            ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd2, stage=1, compute_mode=args.mode,
+                                        device=local_rank, fx_mean=S2[0], fx_std=S2[1])
 
     # ---- CPU baseline: the build's own fp32 restatement on torch-CPU operators + the numpy log-mel
     #      (oracle/ast_torch_cpu.py, pinned against the golden transformers logits in tests/test_oracle.py) on this box's
-    #      host cores: N = 64 windows, both stages for every window (the headline's g = 1.0), 3 repeats, median ----
-    if rank == 0 and world == 1 and not args.no_cpu:
+    #      host cores: N = 64 windows, both stages for every window (the headline's g = 1.0), 3 repeats, median.  Pure
+    #      host code: on an exception it is retried ONCE, single-threaded log-mel, one repeat ----
+    def cpu_leg():
         from oracle import ast_oracle as orc
         from oracle import ast_torch_cpu as tcpu
-        n_cpu = args.cpu_windows
         wins = orc.window_audio(rec[: win + (n_cpu - 1) * hop])
         allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-        r = tcpu.time_two_stage(wins, sd1s, sd2, S1, S2, repeats=args.cpu_repeats, budget_s=args.cpu_budget_s)
+        budget = min(args.cpu_budget_s, args.time_budget_s - (time.perf_counter() - t_bench0) - 10.0)
+        retried = None
+        try:
+            r = tcpu.time_two_stage(wins, sens1, sens2, S1, S2, repeats=args.cpu_repeats, budget_s=budget)
+        except Exception as e:      # noqa: BLE001
+            traceback.print_exc(file=sys.stderr)
+            retried = f"{type(e).__name__}: {e}"
+            budget = min(args.cpu_budget_s, args.time_budget_s - (time.perf_counter() - t_bench0) - 10.0)
+            r = tcpu.time_two_stage(wins, sens1, sens2, S1, S2, repeats=1, budget_s=budget, mel_threads=1)
         out["cpu_baseline"] = {"value": n_cpu / r["seconds"], "unit": "windows/s", "cores": r["threads"], "kind": "port",
                                "mel_windows_per_s_per_stage": 2 * n_cpu / r["mel_seconds"],
                                "forward_windows_per_s_per_stage": 2 * n_cpu / r["forward_seconds"],
@@ -361,21 +462,73 @@ def main():
                                          f"{args.cpu_repeats}), {r['seconds']:.1f} s each (mel {r['mel_seconds']:.1f} s, forward "
                                          f"{r['forward_seconds']:.1f} s); {r['threads']} threads = cores this process may use "
                                          f"(affinity {allowed}, cgroup quota applied), os.cpu_count {os.cpu_count()}"}
-        # re-run the headline mode once so the comparison is against its logits
-        step()
-        barrier()
-        out["parity_in_bench"] = {"stage1_logit_max_abs_err_vs_cpu_restatement": float(
-            np.abs(s1_logits[:n_cpu] - r["logits1"]).max()), "windows": n_cpu,
-            "note": "checker = oracle/ast_torch_cpu.py (fp32, numpy-branch log-mel: the extractor branch this build pins; a "
-                    "torchaudio-equipped reference install takes the kaldi fp32 branch, see DESIGN.md (c))"}
+        if retried:
+            out["cpu_baseline"]["first_attempt_error"] = retried
+        if gpu_sens:
+            e1 = np.abs(gpu_sens[0] - r["logits1"]).max(axis=1)
+            e2 = np.abs(gpu_sens[1] - r["logits2"]).max(axis=1)
+            ref = np.concatenate([r["logits1"], r["logits2"]])
+            out["parity_in_bench"] = {
+                "weight_set": "sens (input-sensitive; seeds 31 / 33), both stages", "windows": n_cpu, "dtype": args.mode,
+                "stage1_logit_max_abs_err_vs_cpu_restatement": float(e1.max()),
+                "stage2_logit_max_abs_err_vs_cpu_restatement": float(e2.max()),
+                "p99_abs_err": float(np.percentile(np.concatenate([e1, e2]), 99)),
+                "reference_logit_margin_span": [float((ref[:, 1] - ref[:, 0]).min()), float((ref[:, 1] - ref[:, 0]).max())],
+                "tolerance": 1e-3,
+                "note": "checker = oracle/ast_torch_cpu.py (fp32, numpy-branch log-mel: the extractor branch this build pins; a "
+                        "torchaudio-equipped reference install takes the kaldi fp32 branch, see DESIGN.md (c))"}
 
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if world > 1:
-        if use_rccl:
-            ctx.comm_destroy()
-        tdist.destroy_process_group()
+    # Everything below is AUXILIARY: each leg is guarded, a failure is recorded under the leg's key ({"error": ...}) and the
+    # line is still printed (round 3 lost its driver-timed headline to an exception in the CPU leg).  SIGTERM prints the
+    # line with whatever has been measured so far; legs that would run past --time-budget-s are skipped and say so.
+    out["legs"] = {}
+    emitted = []
+
+    def emit():
+        if rank == 0 and not emitted:
+            emitted.append(1)
+            out["bench_seconds"] = round(time.perf_counter() - t_bench0, 1)
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+    def on_term(signum, _frame):
+        out["legs"]["terminated"] = f"signal {signum} after {time.perf_counter() - t_bench0:.0f} s"
+        emit()
+        os._exit(0 if rank == 0 else 1)
+
+    signal.signal(signal.SIGTERM, on_term)
+
+    def leg(name, fn, need_s=0.0, when=True):
+        """run one auxiliary leg; never raises"""
+        if not when:
+            return
+        t0 = time.perf_counter()
+        left = args.time_budget_s - (t0 - t_bench0)
+        if left < need_s:
+            out["legs"][name] = f"skipped: {left:.0f} s left of --time-budget-s {args.time_budget_s:.0f}, leg needs ~{need_s:.0f}"
+            return
+        try:
+            fn()
+            out["legs"][name] = f"ok {time.perf_counter() - t0:.1f} s"
+        except Exception as e:      # noqa: BLE001 — an auxiliary leg must never void the headline
+            traceback.print_exc(file=sys.stderr)
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            out["legs"][name] = f"FAILED after {time.perf_counter() - t0:.1f} s"
+
+    single = rank == 0 and world == 1 and not args.headline_only
+    try:
+        leg("gate_sweep", lambda: gate_sweep(), need_s=15, when=not args.no_sweep)
+        leg("x3_fast_modes", lambda: other_modes(), need_s=15, when=not args.no_fast and args.mode == "f16c8")
+        leg("config1_stage1_b256", lambda: config1(), need_s=10, when=single)
+        leg("resample_48k_to_16k", lambda: resample_leg(), need_s=10, when=single)
+        leg("parity_gpu_sens", lambda: parity_gpu(), need_s=10, when=single and not args.no_cpu)
+        leg("cpu_baseline", lambda: cpu_leg(), need_s=45, when=single and not args.no_cpu)
+    finally:
+        emit()
+        if world > 1:
+            if use_rccl:
+                ctx.comm_destroy()
+            tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

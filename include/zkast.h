@@ -165,7 +165,7 @@ int zk_audio_get(zk_ctx* ctx, float* out /*host|device*/, int64_t* n_samples);
 /* ---- introspection / measurement ---------------------------------------------------------------------------- */
 /* per-kernel-class HIP-event timing over the calls made since zk_prof_begin (on the context's stream).
  * zk_prof_get: name in {"gemm_qkv","gemm_o","gemm_fc1","gemm_fc2","gemm_patch","attention","layernorm","logmel",
- * "embed","head"} -> accumulated milliseconds and launch count.                                                   */
+ * "embed","head","wav_decode","resample"} -> accumulated milliseconds and launch count.                           */
 int zk_prof_begin(zk_ctx* ctx);
 int zk_prof_end(zk_ctx* ctx);
 int zk_prof_get(zk_ctx* ctx, const char* name, double* ms, int64_t* launches);

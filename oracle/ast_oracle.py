@@ -95,16 +95,16 @@ def hann_window() -> np.ndarray:
     return 0.5 - 0.5 * np.cos(2.0 * np.pi * n / (FRAME_LEN - 1))
 
 
-_MEL = None
-_HANN = None
+# Built once at import and published as ONE immutable tuple: there is no lazily initialised state a worker thread of
+# ast_torch_cpu.extract_features_parallel could observe half-built (round 3's bench died on exactly that: `_MEL` was
+# assigned before `_HANN`, a second thread saw `_MEL is not None` and got `(mel, None)`).
+_CONSTS = (mel_filter_bank_kaldi(), hann_window())
+for _a in _CONSTS:
+    _a.setflags(write=False)
 
 
 def _consts():
-    global _MEL, _HANN
-    if _MEL is None:
-        _MEL = mel_filter_bank_kaldi()
-        _HANN = hann_window()
-    return _MEL, _HANN
+    return _CONSTS
 
 
 # --------------------------------------------------------------------------------------------------
@@ -452,17 +452,18 @@ def fp8_e4m3_bits(x: np.ndarray) -> np.ndarray:
     return (sign | (exp_field.astype(np.uint8) << 3) | man.astype(np.uint8)).astype(np.uint8)
 
 
-_E4M3_LUT = None
+def _e4m3_lut() -> np.ndarray:
+    b = np.arange(256)
+    s_, e_, m_ = b >> 7, (b >> 3) & 15, b & 7
+    v = np.where(e_ == 0, m_ * 2.0 ** -9, (8 + m_) * np.exp2(e_ - 10.0))
+    return np.where(s_ == 1, -v, v).astype(np.float32)
+
+
+_E4M3_LUT = _e4m3_lut()          # import-time constant, like _CONSTS: no lazily built module state anywhere in the oracle
 
 
 def fp8_e4m3_round(x: np.ndarray) -> np.ndarray:
     """x rounded to the nearest e4m3 value (clamped to +-448), as float32."""
-    global _E4M3_LUT
-    if _E4M3_LUT is None:
-        b = np.arange(256)
-        s_, e_, m_ = b >> 7, (b >> 3) & 15, b & 7
-        v = np.where(e_ == 0, m_ * 2.0 ** -9, (8 + m_) * np.exp2(e_ - 10.0))
-        _E4M3_LUT = np.where(s_ == 1, -v, v).astype(np.float32)
     return _E4M3_LUT[fp8_e4m3_bits(x)]
 
 

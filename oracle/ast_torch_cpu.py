@@ -109,32 +109,35 @@ class TorchAST:
 
 
 def time_two_stage(windows, sd1, sd2, fx1, fx2, repeats: int = 3, threads: int | None = None,
-                   budget_s: float = 150.0):
+                   budget_s: float = 150.0, mel_threads: int | None = None):
     """Median wall time of (log-mel + forward) x 2 stages over `windows`, every window through both stages (the bench's
     g = 1.0 workload).  Stops repeating early rather than exceed `budget_s` (the bench line says how many repeats ran).
-    -> dict(seconds, mel_seconds, forward_seconds, repeats, threads, logits1)."""
+    `mel_threads` = size of the log-mel thread pool (default: `threads`; 1 = no pool concurrency, bench.py's retry).
+    -> dict(seconds, mel_seconds, forward_seconds, repeats, threads, logits1, logits2)."""
     import torch
     threads = threads or effective_cpus()
+    mel_threads = mel_threads or threads
     prev = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
         m1, m2 = TorchAST(sd1), TorchAST(sd2)
-        runs, t_start, l1 = [], time.perf_counter(), None
+        runs, t_start, l1, l2 = [], time.perf_counter(), None, None
         for _ in range(max(1, repeats)):
             t0 = time.perf_counter()
-            f1 = extract_features_parallel(windows, fx1[0], fx1[1], threads)
+            f1 = extract_features_parallel(windows, fx1[0], fx1[1], mel_threads)
             t1 = time.perf_counter()
             l1 = m1.forward(f1)
             t2 = time.perf_counter()
-            f2 = extract_features_parallel(windows, fx2[0], fx2[1], threads)
+            f2 = extract_features_parallel(windows, fx2[0], fx2[1], mel_threads)
             t3 = time.perf_counter()
-            m2.forward(f2)
+            l2 = m2.forward(f2)
             t4 = time.perf_counter()
             runs.append((t4 - t0, (t1 - t0) + (t3 - t2), (t2 - t1) + (t4 - t3)))
             if (time.perf_counter() - t_start) + runs[-1][0] > budget_s:
                 break
         runs.sort()
         tot, mel, fwd = runs[len(runs) // 2]
-        return dict(seconds=tot, mel_seconds=mel, forward_seconds=fwd, repeats=len(runs), threads=threads, logits1=l1)
+        return dict(seconds=tot, mel_seconds=mel, forward_seconds=fwd, repeats=len(runs), threads=threads, logits1=l1,
+                    logits2=l2)
     finally:
         torch.set_num_threads(prev)

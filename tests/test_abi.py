@@ -55,3 +55,35 @@ def test_product_path_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert not pat.search(text), (dirpath, fn)
+
+
+def test_library_has_no_hard_wired_hip_runtime():
+    """libzkast.so must not carry DT_NEEDED libamdhip64 / a RUNPATH into one ROCm tree: it binds to the process's runtime
+    (zkast/lib.py::_ensure_hip_runtime), otherwise a torch wheel's own runtime makes two (round 3: "No HIP GPUs")."""
+    import subprocess
+    if not os.path.exists(lib.LIB_PATH):
+        lib.build()
+    dyn = subprocess.run(["readelf", "-d", lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libamdhip64" not in dyn and "RUNPATH" not in dyn and "RPATH" not in dyn, dyn
+
+
+def test_one_hip_runtime_image_whatever_the_import_order():
+    """fresh processes, both orders: after zkast AND torch are loaded exactly one libamdhip64 and one libhsa-runtime64
+    image is mapped (no GPU needed: loading is enough)."""
+    import subprocess
+    import sys
+    body = (
+        "import os, sys\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'zenker-audio-detection_amd')!r})\n"
+        "{first}\n{second}\n"
+        "from zkast import lib\n"
+        "hip, hsa = lib._mapped_libraries('libamdhip64'), lib._mapped_libraries('libhsa-runtime64')\n"
+        "assert len(hip) == 1 and len(hsa) <= 1, (hip, hsa)\n"
+        "assert os.path.samefile(hip[0], lib.HIP_RUNTIME_PATH) or not lib.HIP_RUNTIME_PATH.startswith('/'), (hip, lib.HIP_RUNTIME_PATH)\n"
+        "print('ok', hip[0])\n")
+    zk = "from zkast import lib; lib.load_library()"
+    th = "import torch"
+    for first, second in ((zk, th), (th, zk)):
+        r = subprocess.run([sys.executable, "-c", body.format(first=first, second=second)], capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0 and r.stdout.startswith("ok"), (first, r.stdout, r.stderr[-2000:])

@@ -425,3 +425,31 @@ def test_error_behaviour_matches_contract():
     # a failed load leaves the slot unloaded and says so
     with pytest.raises(lib.ZkError, match="no model loaded"):
         ctx.ast_forward(1, None, None, 1, np.zeros((1, 2), np.float32))
+
+
+@pytest.mark.gpu
+def test_torch_comes_up_after_the_library_has_used_the_gpu():
+    """Round 3's integration hazard, in a FRESH process and in the order that failed: libzkast.so runs kernels first,
+    torch's device context is created afterwards.  One HIP runtime image, both sides compute."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys\n"
+        f"sys.path.insert(0, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'zenker-audio-detection_amd')!r})\n"
+        "import numpy as np\n"
+        "from zkast import lib, synth\n"
+        "ctx = lib.get_context(0)\n"
+        "rec = synth.synth_recording(1, 48000)\n"
+        "ctx.logmel(rec, rec.size, 0, 8000, 16000, 5)\n"
+        "f = ctx.features_get()\n"
+        "assert f.shape == (5, 98, 128) and np.isfinite(f).all()\n"
+        "import torch\n"
+        "t = (torch.ones(1000, device='cuda') * 2).sum().item()\n"
+        "assert t == 2000.0\n"
+        "ctx.logmel(rec, rec.size, 0, 8000, 16000, 5)\n"
+        "assert np.array_equal(ctx.features_get(), f)\n"
+        "hip = lib._mapped_libraries('libamdhip64')\n"
+        "assert len(hip) == 1, hip\n"
+        "print('ok', hip[0])\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

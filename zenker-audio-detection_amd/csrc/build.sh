@@ -32,11 +32,15 @@ done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 objs=()
 for f in $PRODUCT; do [ -f "$OBJ/$f.o" ] && objs+=("$OBJ/$f.o"); done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIBNAME" "${objs[@]}" -ldl ${ZK_LINK_LIBS:-}
+# -no-hip-rt: NO DT_NEEDED on libamdhip64 (and no RUNPATH into one ROCm tree).  The library binds to the HIP runtime the
+# host process has loaded (zkast/lib.py::_ensure_hip_runtime loads exactly one, RTLD_GLOBAL; a C host links -lamdhip64
+# itself).  With a hard-wired /opt/rocm runtime a process that also imports a PyTorch wheel (which
+# ships its own, SONAME-less libamdhip64.so) ended up with two HIP + two HSA runtimes: "No HIP GPUs are available".
+$HIPCC --offload-arch=gfx950 -shared -fPIC -no-hip-rt -o "$OUT/$LIBNAME" "${objs[@]}" -ldl ${ZK_LINK_LIBS:-}
 echo "built $OUT/$LIBNAME"
 if [ "${ZK_PROBES:-0}" = "1" ]; then
   pobjs=("${objs[@]}")
   for f in $PROBES; do [ -f "$OBJ/$f.o" ] && pobjs+=("$OBJ/$f.o"); done
-  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${ZK_PROBES_NAME:-libzkast_probes.so}" "${pobjs[@]}" -ldl ${ZK_LINK_LIBS:-}
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -no-hip-rt -o "$OUT/${ZK_PROBES_NAME:-libzkast_probes.so}" "${pobjs[@]}" -ldl ${ZK_LINK_LIBS:-}
   echo "built $OUT/${ZK_PROBES_NAME:-libzkast_probes.so}"
 fi

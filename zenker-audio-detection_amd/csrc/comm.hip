@@ -5,11 +5,16 @@
 // sharding itself lives in zkast/dist.py.
 //
 // RCCL is dlopen()ed on first use: libzkast.so has no link-time dependency on it and single-GPU use never loads it.
+// It must be the RCCL that belongs to the HIP runtime this process already uses (libzkast.so itself binds to whichever
+// libamdhip64 the host loaded, see zkast/lib.py): a PyTorch wheel ships its own libamdhip64.so + librccl.so, and an RCCL
+// from another ROCm tree would pull a SECOND HIP / HSA runtime into the process.  So the first candidate is the librccl
+// that lies next to the runtime `hipStreamSynchronize` resolved to (dladdr), then $ZKAST_RCCL_LIB, then the system names.
 #include "../../include/zkast.h"
 #include "zk_common.h"
 
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -34,14 +39,30 @@ struct RcclApi {
   int (*CommDestroy)(rccl_comm_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
-  std::string err;
+  std::string err, path;
   bool load() {
     if (handle) return true;
-    for (const char* name : {"librccl.so.1", "librccl.so"}) {
-      handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (handle) break;
+    std::string tried;
+    auto attempt = [&](const std::string& name) {
+      if (handle || name.empty()) return;
+      handle = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (handle) path = name; else tried += (tried.empty() ? "" : ", ") + name;
+    };
+    if (const char* e = getenv("ZKAST_RCCL_LIB")) attempt(e);
+    Dl_info info;
+    memset(&info, 0, sizeof info);
+    if (dladdr((const void*)&hipStreamSynchronize, &info) && info.dli_fname) {      // directory of the HIP runtime in use
+      std::string dir = info.dli_fname;
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) {
+        dir.resize(slash + 1);
+        attempt(dir + "librccl.so.1");
+        attempt(dir + "librccl.so");
+      }
     }
-    if (!handle) { err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "?"); return false; }
+    attempt("librccl.so.1");
+    attempt("librccl.so");
+    if (!handle) { err = "RCCL not found (tried " + tried + "): " + (dlerror() ? dlerror() : "?"); return false; }
 #define ZK_SYM(field, sym) field = (decltype(field))dlsym(handle, sym); if (!field) { err = std::string("RCCL lacks ") + sym; handle = nullptr; return false; }
     ZK_SYM(GetUniqueId, "ncclGetUniqueId")
     ZK_SYM(CommInitRank, "ncclCommInitRank")

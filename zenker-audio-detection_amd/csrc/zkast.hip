@@ -96,9 +96,10 @@ struct StageModel {
   }
 };
 
-enum ProfClass { P_GEMM_QKV, P_GEMM_O, P_GEMM_FC1, P_GEMM_FC2, P_GEMM_PATCH, P_ATTN, P_LN, P_LOGMEL, P_EMBED, P_HEAD, P_N };
+enum ProfClass { P_GEMM_QKV, P_GEMM_O, P_GEMM_FC1, P_GEMM_FC2, P_GEMM_PATCH, P_ATTN, P_LN, P_LOGMEL, P_EMBED, P_HEAD, P_WAVDEC,
+                 P_RESAMPLE, P_N };
 const char* kProfNames[P_N] = {"gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch",
-                               "attention", "layernorm", "logmel", "embed", "head"};
+                               "attention", "layernorm", "logmel", "embed", "head", "wav_decode", "resample"};
 
 }  // namespace
 
@@ -985,7 +986,7 @@ int zk_wav_decode(zk_ctx* c, const void* data, int64_t n_bytes, int32_t format_t
   const bool dev = is_device_ptr(out);
   float* d_out = out;
   if (!dev) { HIPCHK(c, c->st_out.ensure((size_t)n_frames * 4)); d_out = c->st_out.as<float>(); }
-  zk_launch_wav_decode((const unsigned char*)d_in, n_frames, format_tag, bits, channels, d_out, c->stream);
+  { ProfScope ps(c, P_WAVDEC); zk_launch_wav_decode((const unsigned char*)d_in, n_frames, format_tag, bits, channels, d_out, c->stream); }
   HIPCHK(c, hipGetLastError());
   if (!dev) return from_device(c, d_out, out, (size_t)n_frames * 4);
   return finish(c);
@@ -1031,7 +1032,7 @@ int zk_resample(zk_ctx* c, const float* in, int64_t n_in, int32_t orig_sr, int32
   const bool dev = is_device_ptr(out);
   float* d_out = out;
   if (!dev) { HIPCHK(c, c->st_out.ensure((size_t)n_out * 4)); d_out = c->st_out.as<float>(); }
-  zk_launch_resample((const float*)d_in, n_in, orig, neu, c->rs_width, c->rs_kern.as<float>(), c->rs_klen, d_out, n_out, c->stream);
+  { ProfScope ps(c, P_RESAMPLE); zk_launch_resample((const float*)d_in, n_in, orig, neu, c->rs_width, c->rs_kern.as<float>(), c->rs_klen, d_out, n_out, c->stream); }
   HIPCHK(c, hipGetLastError());
   if (!dev) return from_device(c, d_out, out, (size_t)n_out * 4);
   return finish(c);

@@ -61,6 +61,59 @@ def build(verbose: bool = False) -> str:
 
 _lib = None
 _lib_lock = threading.Lock()
+HIP_RUNTIME_PATH = None      # the libamdhip64 this process's libzkast.so is bound to (set by load_library)
+
+
+def _mapped_libraries(prefix: str) -> list:
+    """paths of the shared objects mapped into this process whose file name starts with `prefix`"""
+    seen = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rstrip("\n").split(None, 5)[-1] if line.count("/") else ""
+                if path.startswith("/") and os.path.basename(path).startswith(prefix) and path not in seen:
+                    seen.append(path)
+    except OSError:
+        pass
+    return seen
+
+
+def _ensure_hip_runtime() -> str:
+    """Exactly ONE HIP runtime per process.  libzkast.so is linked without a DT_NEEDED on libamdhip64 (csrc/build.sh): its
+    hip* symbols resolve against whichever runtime is in the global scope when it is loaded, and this function puts one
+    there, in this order:
+
+      1. a libamdhip64 that is already mapped — the host imported torch first, or is a HIP application itself;
+      2. the one a PyTorch wheel ships (``torch/lib/libamdhip64.so``, located WITHOUT importing torch): a later
+         ``import torch`` then finds its runtime already loaded and shares it;
+      3. the system ROCm (``$ZKAST_HIP_LIB``, ``libamdhip64.so.7`` on the loader path, ``/opt/rocm/lib``).
+
+    Why: a PyTorch-ROCm wheel carries its own SONAME-less ``libamdhip64.so`` + ``libhsa-runtime64.so``; with libzkast.so
+    hard-wired to /opt/rocm's the process held two HIP and two HSA runtimes, and the one that came up second could not
+    acquire the GPU (``RuntimeError: No HIP GPUs are available`` from torch after libzkast had run — round 3,
+    tests/test_model_gpu.py on its own).  The order of imports no longer matters."""
+    mode = getattr(os, "RTLD_GLOBAL", 0x100) | getattr(os, "RTLD_NOW", 0x2)
+    tried = []
+    cands = _mapped_libraries("libamdhip64.so")
+    if not cands:
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec("torch")
+            if spec is not None and spec.origin:
+                p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+                if os.path.exists(p):
+                    cands.append(p)
+        except (ImportError, ValueError):
+            pass
+    cands += [p for p in (os.environ.get("ZKAST_HIP_LIB"), "libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so.7",
+                          "libamdhip64.so") if p]
+    for path in cands:
+        try:
+            C.CDLL(path, mode=mode)      # an already-mapped file is not loaded again, only promoted to the global scope
+            return path
+        except OSError as e:
+            tried.append(f"{path}: {e}")
+    raise ZkError("no HIP runtime (libamdhip64) could be loaded; zkast has no CPU fallback.  Tried: " + "; ".join(tried))
 
 
 def load_library() -> C.CDLL:
@@ -71,6 +124,8 @@ def load_library() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ZkError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(zkast has no CPU fallback; the HIP library is the product)")
+        global HIP_RUNTIME_PATH
+        HIP_RUNTIME_PATH = _ensure_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
         sig = {
@@ -149,7 +204,7 @@ def _ptr(x):
 
 
 PROF_CLASSES = ["gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention", "layernorm", "logmel",
-                "embed", "head"]
+                "embed", "head", "wav_decode", "resample"]
 
 
 class Context:
