@@ -178,6 +178,15 @@ int zk_debug_set_tap(zk_ctx* ctx, int32_t layer);
 int zk_debug_get_tap(zk_ctx* ctx, float* out /*host*/, int32_t n_windows);
 
 /* ---- test hooks: run ONE kernel on caller-provided fp32 HOST data (tests/test_kernels_gpu.py) ------------------ */
+/* Flags ORed into `epi` (zk_test_gemm) or `nsplit` (zk_test_layernorm, zk_test_attention), ZK_F16C8 only: the kernel reads
+ * its x planes (TILED_IN, GEMM) / writes its output planes (TILED_OUT: LayerNorm, attention, the GEMM's GELU epilogue)
+ * in the k-slice-major tile layout the forward uses between its GEMM-side kernels; results must equal the row-major
+ * ones bit for bit.                                                                                                 */
+#define ZK_TEST_TILED_IN 0x100
+#define ZK_TEST_TILED_OUT 0x200
+/* zk_test_gemm: the rows M .. ceil(M/256)*256 of the hook's x planes hold NaN patterns instead of zeros (the ZK_F16C8
+ * kernel reads its last row block whole; what lies behind row M must never reach a result)                           */
+#define ZK_TEST_POISON_PAD 0x400
 /* LayerNorm(768): x (rows,768) -> out (rows,768) = hi (+ lo when nsplit is 3 or 2) of the output planes            */
 int zk_test_layernorm(zk_ctx* ctx, const float* x, const float* gamma, const float* beta, int32_t rows, float eps,
                       int32_t nsplit, float* out);

@@ -361,3 +361,94 @@ def test_window_audio_views_equal_the_oracle_windows():
         assert len(got) == len(ref) and all(np.array_equal(g, r) for g, r in zip(got, ref))
     full = pl.window_audio(np.arange(40000, dtype=np.float32), 1.0, 0.5)
     assert full[1].base is not None and full[1][0] == 8000.0          # strided view, not a copy
+
+
+def test_cache_write_failures_never_stop_the_inference(tmp_path, monkeypatch):
+    """torch.save reports a full disk as RuntimeError, the (N,1024,128) expansion of the `.pt` twin can raise
+    MemoryError — the reference catches Exception around its cache write (..._cache.py:181-192) and carries on.  store()
+    must do the same, write the two files independently and leave no `.part` file behind."""
+    from zkast import cache
+    fx = ZkASTFeatureExtractor(mean=-1.1509622, std=3.5340312)
+    wav = tmp_path / "p007_long.wav"
+    pl.write_wav_pcm16(str(wav), np.zeros(16000 + 5 * 8000, np.float32), 16000)
+    feats = cache.CompactFeatures(_fake_logmel(6))
+    key = cache.EntryKey.of(str(wav), 1.0, 0.5, 16000, cache.get_fx_fingerprint(fx))
+    logs = []
+    store = cache.FeatureCache(str(tmp_path / "c"), log=logs.append)
+    compact_path, bundle_path = store._paths(key)
+
+    def full_disk(*_a, **_k):
+        raise RuntimeError("[enforce fail at inline_container.cc] . PytorchStreamWriter failed writing file data/0: file write failed")
+
+    monkeypatch.setattr(cache, "write_reference_bundle", full_disk)
+    store.store(key, feats, fx)                                        # must not raise
+    assert os.path.exists(compact_path) and not os.path.exists(bundle_path)
+    assert any("could not write" in l and "RuntimeError" in l for l in logs)
+    os.remove(compact_path)
+
+    monkeypatch.setattr(cache.CompactFeatures, "expand", lambda self, fx: (_ for _ in ()).throw(MemoryError("1.9 GiB")))
+    store.store(key, feats, fx)
+    assert os.path.exists(compact_path) and any("MemoryError" in l for l in logs)
+    os.remove(compact_path)
+    monkeypatch.undo()
+
+    real_savez = np.savez
+
+    def failing_savez(f, **kw):
+        f.write(b"partial")
+        raise OSError(28, "No space left on device")
+
+    monkeypatch.setattr(np, "savez", failing_savez)
+    store.store(key, feats, fx)                                        # compact store fails, the twin is still written
+    monkeypatch.setattr(np, "savez", real_savez)
+    assert not os.path.exists(compact_path) and os.path.exists(bundle_path)
+    assert not [f for f in os.listdir(tmp_path / "c") if f.endswith(".part")]
+    got = store.lookup(key, 6, fx)                                     # and is usable on the next run
+    assert got is not None and np.abs(got.logmel - feats.logmel).max() <= 2e-6
+
+
+def test_wav_header_reads_headers_only_and_degenerate_formats_count_as_empty(tmp_path):
+    """the frame count for discover_two_files comes from the RIFF chunk headers (no sample bytes are read) and
+    a header with zero channels / zero bits is an empty recording, not a ZeroDivisionError out of the discovery."""
+    import struct
+    p = tmp_path / "a.wav"
+    pl.write_wav_pcm16(str(p), np.zeros(48000 * 3 + 1, np.float32), 48000)
+    tag, ch, sr, bits, nbytes = pl.wav_header(str(p))
+    assert (tag, ch, sr, bits, nbytes) == (1, 1, 48000, 16, 2 * (48000 * 3 + 1))
+    assert pl._wav_num_frames(str(p)) == 48000 * 3 + 1
+    assert pl._length_after_resampling(48000 * 3 + 1, 48000) == 48001 and pl._length_after_resampling(777, 16000) == 777
+    assert pl._length_after_resampling(44100, 44100) == 16000
+    # same numbers as the full parser
+    t2, c2, s2, b2, raw = pl.parse_wav(str(p))
+    assert (t2, c2, s2, b2, len(raw)) == (tag, ch, sr, bits, nbytes)
+    # a LIST chunk in front of the data chunk, odd-sized (padded) — and a data chunk longer than the file (truncated copy)
+    body = struct.pack("<HHIIHH", 1, 2, 16000, 64000, 4, 16)
+    blob = (b"RIFF" + struct.pack("<I", 0) + b"WAVE" + b"LIST" + struct.pack("<I", 3) + b"abc\0"
+            + b"fmt " + struct.pack("<I", 16) + body + b"data" + struct.pack("<I", 4000) + b"\0" * 400)
+    q = tmp_path / "b.wav"
+    q.write_bytes(blob)
+    assert pl.wav_header(str(q)) == (1, 2, 16000, 16, 400) and pl._wav_num_frames(str(q)) == 100
+    # zero channels: counts as length 0
+    z = tmp_path / "z.wav"
+    z.write_bytes(b"RIFF" + struct.pack("<I", 0) + b"WAVE" + b"fmt " + struct.pack("<I", 16)
+                  + struct.pack("<HHIIHH", 1, 0, 16000, 0, 0, 16) + b"data" + struct.pack("<I", 8) + b"\0" * 8)
+    assert pl._wav_num_frames(str(z)) == 0
+    (tmp_path / "n.wav").write_bytes(b"not a wave file at all")
+    assert pl._wav_num_frames(str(tmp_path / "n.wav")) == 0 and pl._wav_num_frames(str(tmp_path / "missing.wav")) == 0
+
+
+def test_window_audio_returns_plain_slices_like_the_reference():
+    """writable views that alias the recording (the reference's `audio[s:s+win]`), not read-only strided views"""
+    a = np.arange(40000, dtype=np.float32)
+    w = pl.window_audio(a, 1.0, 0.5)
+    assert len(w) == 4 and all(x.base is a and x.flags.writeable for x in w)
+    w[1][0] = -1.0
+    assert a[8000] == -1.0 and w[0][8000] == -1.0
+
+
+def test_one_feature_store_serves_both_stages_only_when_the_extractors_differ_in_stats_alone():
+    a = ZkASTFeatureExtractor(mean=-1.15, std=3.53)
+    b = ZkASTFeatureExtractor(mean=-6.5, std=2.75)
+    assert pl._extractors_differ_only_in_stats(a, b) and pl._extractors_differ_only_in_stats(a, a)
+    c = ZkASTFeatureExtractor(mean=-6.5, std=2.75, do_normalize=False)
+    assert not pl._extractors_differ_only_in_stats(a, c)

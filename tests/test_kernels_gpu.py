@@ -375,3 +375,79 @@ def test_wav_source_slices_are_the_whole_recording_bit_for_bit(ctx):
             part = ctx.audio_get()
             assert nbytes <= len(src.raw) and np.array_equal(part[off: off + (a1 - a0)], full[a0:a1]), (sr, a0, a1)
         assert src.load(ctx, 8000, 24000)[1] < len(src.raw) // 3          # a slice uploads a slice
+
+
+# ---- the k-slice-major tile layout of the ZK_F16C8 forward (zk_planes::tiled) at kernel level ----------------------------------
+# Every producer / consumer pair of the forward (LayerNorm -> QKV / FC1, FC1 -> FC2, attention -> O) hands its planes over in
+# tiles; the end-to-end goldens exercise that only at K = 768 / 3072 with M = whole windows.  Here each kernel runs once
+# row-major and once tiled on the same data: the results must be bit-identical, also when M is not a multiple of the
+# 256-row tile (the GEMM stages the last row block whole: rows >= M are read as they lie and must never reach a store).
+@pytest.mark.parametrize("M,N,K,epi", [(300, 768, 768, "store"), (515, 3072, 768, "gelu"), (257, 768, 3072, "resid"),
+                                       (1214 * 2, 2304, 768, "store"), (255, 768, 768, "resid"), (256, 3072, 768, "gelu")])
+def test_gemm_c8_tiled_operands_equal_row_major(ctx, M, N, K, epi):
+    from zkast import lib
+    rng = np.random.default_rng(M * 7 + N + K)
+    x = (rng.normal(0, 1.0, (M, K)) * np.exp(rng.normal(0, 1.0, (M, 1)))).astype(np.float32)      # rows of different scale
+    w = rng.normal(0, 0.05, (N, K)).astype(np.float32)
+    bias = rng.normal(0, 0.05, (N,)).astype(np.float32)
+    code = {"store": lib.EPI_STORE, "gelu": lib.EPI_GELU, "resid": lib.EPI_RESID}[epi]
+    r0 = rng.normal(0, 4.0, (M, N)).astype(np.float32) if epi == "resid" else None
+    base = ctx.test_gemm(x, w, bias, code, 2, resid=r0)
+    tin = ctx.test_gemm(x, w, bias, code, 2, resid=r0, tiled_in=True)
+    assert np.array_equal(base, tin)
+    if epi == "gelu":      # FC1 writes the operand of FC2 in tiles
+        assert np.array_equal(base, ctx.test_gemm(x, w, bias, code, 2, tiled_out=True))
+        assert np.array_equal(base, ctx.test_gemm(x, w, bias, code, 2, tiled_in=True, tiled_out=True))
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + bias
+    if epi == "gelu":
+        ref = _gelu64(ref)
+    if epi == "resid":
+        ref = ref + r0
+    assert np.abs(base - ref).max() <= 6e-5 * np.abs(ref).max()
+
+
+def test_gemm_c8_rows_beyond_m_never_reach_a_store(ctx):
+    """M = 257: the second row block holds ONE valid row and the kernel stages that block whole.  With the 255 rows
+    behind it poisoned (fp16 NaN patterns in both planes) every result must equal the zero-padded run bit for bit, in
+    every epilogue and in both operand layouts; the launcher itself refuses x planes that do not cover the block."""
+    from zkast import lib
+    rng = np.random.default_rng(21)
+    M, K = 257, 768
+    x = rng.normal(0, 1.0, (M, K)).astype(np.float32)
+    bias3 = rng.normal(0, 0.05, (3072,)).astype(np.float32)
+    for N, epi in ((768, lib.EPI_RESID), (2304, lib.EPI_STORE), (3072, lib.EPI_GELU)):
+        w = rng.normal(0, 0.05, (N, K)).astype(np.float32)
+        r0 = rng.normal(0, 4.0, (M, N)).astype(np.float32) if epi == lib.EPI_RESID else None
+        clean = ctx.test_gemm(x, w, bias3[:N], epi, 2, resid=r0)
+        assert np.all(np.isfinite(clean))
+        for tiled in (False, True):
+            assert np.array_equal(clean, ctx.test_gemm(x, w, bias3[:N], epi, 2, resid=r0, tiled_in=tiled, poison_pad=True))
+
+
+@pytest.mark.parametrize("rows", [37, 256, 700])
+def test_layernorm_tiled_planes_equal_row_major(ctx, rows):
+    rng = np.random.default_rng(rows)
+    x = (rng.normal(0, 3.0, (rows, 768)) + rng.normal(0, 5.0, (rows, 1))).astype(np.float32)
+    x[rows // 2] *= 300.0
+    g = (1 + 0.25 * rng.normal(size=768)).astype(np.float32)
+    b = (0.1 * rng.normal(size=768)).astype(np.float32)
+    base = ctx.test_layernorm(x, g, b, 1e-12, 2)
+    assert np.array_equal(base, ctx.test_layernorm(x, g, b, 1e-12, 2, tiled=True))
+
+
+def test_attention_tiled_output_equals_row_major(ctx):
+    rng = np.random.default_rng(12)
+    qkv = rng.normal(0, 1.2, (2 * 1214, 2304)).astype(np.float32)      # 2 428 rows: 9.5 row blocks
+    base = ctx.test_attention(qkv, 2, 2)
+    assert np.array_equal(base, ctx.test_attention(qkv, 2, 2, tiled=True))
+
+
+def test_tiled_flags_are_refused_outside_f16c8(ctx):
+    from zkast import lib
+    x = np.zeros((16, 768), np.float32)
+    with pytest.raises(lib.ZkError):
+        ctx.test_gemm(x, np.zeros((256, 768), np.float32), np.zeros(256, np.float32), lib.EPI_STORE, 3, tiled_in=True)
+    with pytest.raises(lib.ZkError):
+        ctx.test_gemm(x, np.zeros((256, 768), np.float32), np.zeros(256, np.float32), lib.EPI_STORE, 2, tiled_out=True)
+    with pytest.raises(lib.ZkError):
+        ctx.test_layernorm(x, np.ones(768, np.float32), np.zeros(768, np.float32), 1e-12, 3, tiled=True)

@@ -241,10 +241,18 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
   // running max m_run (log2 domain) is kept NEGATED in a 16-register vector that is the C operand of each score
   // block's first MFMA: the accumulator then holds s - m_run directly and exp2 needs no subtraction.  m_run only
-  // moves when some row's block maximum exceeds it by more than RESCALE_THR (p <= 2^8 is harmless in fp16/fp32);
-  // that rare path rescales O and l — and the scores of the NEXT tile, which were started with the old maximum
-  // (T13-style deferred rescale, wave-uniform branch).
-  constexpr float RESCALE_THR = 8.0f;
+  // moves when some row's block maximum exceeds it by more than RESCALE_THR; that path rescales O and l — and the
+  // scores of the NEXT tile, which were started with the old maximum (T13-style deferred rescale, wave-uniform branch).
+  // The threshold is a PRECISION knob, not only a range guard: the weights go to the P·V MFMA as fp16, and a weight
+  // 2^(s - m_run) is exact exactly when s = m_run.  With the reference far below the row's true maximum (2^8 was
+  // harmless for the range) the DOMINANT key of a peaked row carries a 2^-11 rounding error, which on the
+  // input-sensitive weight set was the largest single term of the logit error (round 4, tools/sens_budget.py: 7.2e-4 at
+  // 2^8, 2.7e-4 at 2^2 or below, where the rescale fires in 9 % of the wave-tiles).  At 2 a key that tops the reference by
+  // more than 4x becomes the new (exact) reference; anything it leaves inexact shares its row with a comparable weight.
+#ifndef ZK_ATT_RESCALE_THR
+#define ZK_ATT_RESCALE_THR 2.0f
+#endif
+  constexpr float RESCALE_THR = ZK_ATT_RESCALE_THR;
   f16_t negm;
 #pragma unroll
   for (int i = 0; i < 16; ++i) negm[i] = 0.f;

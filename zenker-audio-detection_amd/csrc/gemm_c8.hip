@@ -669,8 +669,12 @@ void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
 
 }  // namespace
 
-// Host-side shape contract as zk_launch_gemm: N % 256 == 0, K % 64 == 0, M >= 1; x_lo / w_lo are c8 planes.
-void zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s) {
+// Host-side shape contract as zk_launch_gemm: N % 256 == 0, K % 64 == 0, M >= 1; x_lo / w_lo are c8 planes.  The kernel
+// stages the last 256-row block of x WHOLE (no M-tail clamp in the loader), so the planes must be allocated for
+// ceil(M/256)*256 rows: the caller states the allocation in x_rows and the launch is refused if it falls short.
+int zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s) {
+  if (a.M < 1 || a.N % 256 || a.K % 64) return -1;
+  if (a.x_rows < (int64_t)((a.M + 255) / 256) * 256) return -1;
   switch (epi) {
     case ZK_EPI_STORE: if (a.x_tiled) launch_cfg<ZK_EPI_STORE, true>(a, s); else launch_cfg<ZK_EPI_STORE>(a, s); break;
     case ZK_EPI_GELU:
@@ -682,4 +686,5 @@ void zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s) {
     case ZK_EPI_RESID: if (a.x_tiled) launch_cfg<ZK_EPI_RESID, true>(a, s); else launch_cfg<ZK_EPI_RESID>(a, s); break;
     default: launch_cfg<ZK_EPI_PATCH>(a, s); break;
   }
+  return 0;
 }

@@ -126,7 +126,7 @@ int zkp_bench_gemm_c8(int M, int N, int K, int epi, int variants, int iters, int
   }
   auto args = [&](int v) {
     zk_gemm_args a;
-    a.x_hi = xh; a.x_lo = xl; a.w_hi = wh; a.w_lo = wl; a.bias = bias; a.x_rowexp = nullptr; a.M = M; a.N = N; a.K = K;
+    a.x_hi = xh; a.x_lo = xl; a.w_hi = wh; a.w_lo = wl; a.bias = bias; a.x_rowexp = nullptr; a.M = M; a.N = N; a.K = K; a.x_rows = (M + 255) / 256 * 256;
     a.o_hi = oh[v]; a.o_lo = ol[v]; a.resid = resid[v]; a.pos = nullptr; a.lo_n_limit = N; a.lo_c8_to = epi == ZK_EPI_STORE ? (2 * N) / 3 : 1 << 30;
     a.w_exp = w_exp; a.lo_c8_from = epi == ZK_EPI_STORE ? N / 3 : 1 << 30;
     return a;

@@ -106,7 +106,7 @@ int zkp_bench_gemm_c6(int M, int N, int K, int epi, int iters, int rounds, float
   auto launch = [&](int v) {
     zk_gemm6_args g;
     zk_gemm_args& a = g.a;
-    a.x_hi = xh; a.w_hi = wh; a.bias = bias; a.x_rowexp = nullptr; a.M = M; a.N = N; a.K = K;
+    a.x_hi = xh; a.w_hi = wh; a.bias = bias; a.x_rowexp = nullptr; a.M = M; a.N = N; a.K = K; a.x_rows = (M + 255) / 256 * 256;
     a.o_hi = oh[v]; a.o_lo = ol[v]; a.resid = resid[v]; a.pos = nullptr; a.lo_n_limit = epi == ZK_EPI_STORE ? (2 * N) / 3 : N;
     a.w_exp = w_exp; a.lo_c8_from = epi == ZK_EPI_STORE ? N / 3 : 1 << 30;
     if (v == 0) { a.x_lo = xl; a.w_lo = wl; zk_launch_gemm_c8(a, epi, s); }

@@ -53,6 +53,9 @@ struct zk_planes {
   // the eight 16-byte chunks of a row in the LDS image's swizzled order (chunk c of row m at position c ^ ((m >> 1) & 7)) —
   // so that the X half of a GEMM ring step is 32 KiB contiguous in HBM (gemm_c8.hip).  Planes must hold whole row blocks.
   int tiled = 0;
+  // rows the planes are allocated for (set by the owner of the buffers; 0 = not stated).  zk_launch_gemm_c8 refuses an
+  // x operand whose last 256-row block is not wholly inside the allocation.
+  int64_t rows_cap = 0;
 };
 #ifdef __HIPCC__
 // element offset of columns [c, c + 8) ∩ one 16-byte chunk of row m in a tiled plane with K columns
@@ -136,6 +139,7 @@ struct zk_gemm_args {
   int lo_c8_to = 1 << 30;   //   QKV: the fp8-corrected QK^T), the others an fp16 lo plane (q: re-split by attention; v: the Vl·P pass)
   int w_exp;           // ZK_F16C8: the weight's c8 plane holds (fp8(W·2^w_exp), fp8((W-Wh)·2^(w_exp+11)))
   int rev = 0;         // ZK_F16C8: walk the row blocks from the last to the first (same results, other order)
+  int64_t x_rows = 0;  // ZK_F16C8: rows the x planes are ALLOCATED for; must cover ceil(M/256)*256 (checked by the launcher)
   int x_tiled = 0;     // ZK_F16C8: the x planes are k-slice-major tiles (zk_planes::tiled)
   int o_tiled = 0;     // ZK_F16C8, GELU epilogue: write the output planes that way (the operand of the next GEMM)
 };
@@ -176,4 +180,6 @@ void zk_launch_split_c8(const float* src, int64_t n, int w_exp, int is_weight, h
 // columns [c0, c0 + ncols) of a [rows, ld] fp32 matrix -> activation c8 entries at the same positions of `lo` (ncols % 4 == 0)
 void zk_launch_split_c8_cols(const float* src, int rows, int ld, int c0, int ncols, half_t* lo, hipStream_t s);
 void zk_launch_split_rows_c8(const float* src, int rows, int K, half_t* hi, half_t* c8, int32_t* rowexp, hipStream_t s);
-void zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s);
+// returns 0, or -1 (nothing launched) when the shape / padding contract is violated: N % 256, K % 64, M < 1, or x planes
+// that do not cover the last row block whole (zk_gemm_args::x_rows)
+int zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s);

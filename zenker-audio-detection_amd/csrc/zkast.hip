@@ -60,8 +60,10 @@ struct DevArena {
 struct PlaneBuf {
   DevBuf hi, lo, rowexp;      // rowexp: allocated only for the LayerNorm outputs (zk_planes::rowexp)
   zk_planes get(bool split, int lo_fmt = ZK_LO_F16) const {
-    return zk_planes{hi.as<half_t>(), split ? lo.as<half_t>() : nullptr, lo_fmt,
-                     (split && lo_fmt == ZK_LO_C8) ? rowexp.as<int32_t>() : nullptr};
+    zk_planes pl{hi.as<half_t>(), split ? lo.as<half_t>() : nullptr, lo_fmt,
+                 (split && lo_fmt == ZK_LO_C8) ? rowexp.as<int32_t>() : nullptr};
+    pl.rows_cap = (int64_t)((split && lo.cap < hi.cap ? lo.cap : hi.cap) / 2);      // in ELEMENTS here; run_gemm divides by K
+    return pl;
   }
 };
 
@@ -386,7 +388,7 @@ int next_dir(zk_ctx* c) {
   return d;
 }
 
-void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, int M, int N, int K, int epi, int nsplit,
+int run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, int M, int N, int K, int epi, int nsplit,
               zk_planes out, float* resid, const float* pos, int lo_n_limit, int lo_c8_from = 1 << 30, int rev = 0,
               int lo_c8_to = 1 << 30) {
   ProfScope ps(c, cls);
@@ -400,9 +402,23 @@ void run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias,
   a.rev = rev;
   a.x_tiled = (nsplit == ZK_F16C8) ? x.tiled : 0;
   a.o_tiled = (nsplit == ZK_F16C8 && epi == ZK_EPI_GELU) ? out.tiled : 0;
-  if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
-  else zk_launch_gemm(a, epi, nsplit, c->stream);
+  a.x_rows = x.rows_cap / K;      // (PlaneBuf::get states the allocation in elements)
+  if (nsplit == ZK_F16C8) {
+    if (zk_launch_gemm_c8(a, epi, c->stream))
+      return fail(c, ZK_E_SHAPE, "gemm %s: M=%d N=%d K=%d with x planes of %lld rows violates the launch contract (N%%256, K%%64, "
+                  "x allocated for ceil(M/256)*256 rows)", kProfNames[cls], M, N, K, (long long)a.x_rows);
+  } else zk_launch_gemm(a, epi, nsplit, c->stream);
+  return ZK_OK;
 }
+
+// The patch embedding (0.4 % of a forward's time) runs as the 3-pass fp16 split even in ZK_F16C8: its operand is the
+// INPUT, so its e4m3 correction error reaches every token of every layer — on the input-sensitive weight set it was the
+// largest single GEMM term of the logit error (2.8e-4 of ~5e-4, tools/sens_budget.py), for free to remove.
+#ifndef ZK_PATCH_X3
+#define ZK_PATCH_X3 1
+#endif
+inline int patch_mode(int ns) { return (ZK_PATCH_X3 && ns == ZK_F16C8) ? ZK_F16X3 : ns; }
+inline int patch_lo_fmt(int ns) { return patch_mode(ns) == ZK_F16C8 ? ZK_LO_C8 : ZK_LO_F16; }
 
 #ifndef ZK_MID_TILED
 #define ZK_MID_TILED 1      // 0: row-major GELU planes between FC1 and FC2 (A/B switch)
@@ -421,7 +437,7 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
   const int lf = (ns == ZK_F16C8) ? ZK_LO_C8 : ZK_LO_F16;
   const int M = nb * ZK_SEQ;
   float* hidden = c->hidden.as<float>();
-  zk_planes pa = c->patchA.get(sp, lf), xn = c->xn.get(sp, lf), qkv = c->qkv.get(sp), att = c->att.get(sp, lf),
+  zk_planes pa = c->patchA.get(sp, patch_lo_fmt(ns)), xn = c->xn.get(sp, lf), qkv = c->qkv.get(sp), att = c->att.get(sp, lf),
             mid = c->mid.get(sp, lf);
   // ZK_F16C8: the big GEMM operands that a GEMM-side kernel both writes and reads go as k-slice-major tiles
   // (zk_planes::tiled; the workspace planes hold whole 256-row blocks): LayerNorm -> QKV / FC1, FC1 -> FC2, attention -> O
@@ -430,8 +446,8 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
     ProfScope ps(c, P_EMBED);
     zk_launch_cls_rows(hidden, sm.cls, sm.dist, sm.pos, nb, c->stream);
   }
-  run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w, sm.patch_b, nb * ZK_NPATCH, ZK_HIDDEN, ZK_PATCH_K,
-           ZK_EPI_PATCH, ns, zk_planes{nullptr, nullptr, 0}, hidden, sm.pos, 0);
+  if (int grc = run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w, sm.patch_b, nb * ZK_NPATCH, ZK_HIDDEN, ZK_PATCH_K,
+           ZK_EPI_PATCH, patch_mode(ns), zk_planes{nullptr, nullptr, 0}, hidden, sm.pos, 0)) return grc;
   if (c->tap_layer == -1) {
     HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
     HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -448,8 +464,8 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
     { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, M, xn, sm.eps, c->stream, next_dir(c)); }
     // lo planes of the fused QKV: q fp16 (re-split by attention), k c8 byte pairs in ZK_F16C8 (fp8-corrected QK^T) else
     // fp16, v fp16 (attention's Vl·P pass)
-    run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, M, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv,
-             nullptr, nullptr, 3 * ZK_HIDDEN, ns == ZK_F16C8 ? ZK_HIDDEN : 1 << 30, next_dir(c), 2 * ZK_HIDDEN);
+    if (int grc = run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, M, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv,
+             nullptr, nullptr, 3 * ZK_HIDDEN, ns == ZK_F16C8 ? ZK_HIDDEN : 1 << 30, next_dir(c), 2 * ZK_HIDDEN)) return grc;
     {
       ProfScope ps(c, P_ATTN);
       const int qt = last ? 1 : 10;
@@ -460,23 +476,23 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
       zk_planes att_s = c->att_s.get(sp, lf), xn_s = c->xn_s.get(sp, lf), mid_s = c->mid_s.get(sp, lf);
       float* hs = c->hidden_s.as<float>();
       { ProfScope ps(c, P_EMBED); zk_launch_gather_tok01(att, hidden, nb, att_s, hs, c->stream); }
-      run_gemm(c, P_GEMM_O, att_s, L.wo, L.bo, 2 * nb, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
-               zk_planes{nullptr, nullptr, 0}, hs, nullptr, 0);
+      if (int grc = run_gemm(c, P_GEMM_O, att_s, L.wo, L.bo, 2 * nb, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
+               zk_planes{nullptr, nullptr, 0}, hs, nullptr, 0)) return grc;
       { ProfScope ps(c, P_LN); zk_launch_layernorm(hs, ZK_HIDDEN, L.ln2_g, L.ln2_b, 2 * nb, xn_s, sm.eps, c->stream); }
-      run_gemm(c, P_GEMM_FC1, xn_s, L.w1, L.b1, 2 * nb, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid_s, nullptr,
-               nullptr, ZK_INTER);
-      run_gemm(c, P_GEMM_FC2, mid_s, L.w2, L.b2, 2 * nb, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
-               zk_planes{nullptr, nullptr, 0}, hs, nullptr, 0);
+      if (int grc = run_gemm(c, P_GEMM_FC1, xn_s, L.w1, L.b1, 2 * nb, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid_s, nullptr,
+               nullptr, ZK_INTER)) return grc;
+      if (int grc = run_gemm(c, P_GEMM_FC2, mid_s, L.w2, L.b2, 2 * nb, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
+               zk_planes{nullptr, nullptr, 0}, hs, nullptr, 0)) return grc;
       pruned = true;
       continue;
     }
-    run_gemm(c, P_GEMM_O, att, L.wo, L.bo, M, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
-             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c));
+    if (int grc = run_gemm(c, P_GEMM_O, att, L.wo, L.bo, M, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
+             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c))) return grc;
     { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln2_g, L.ln2_b, M, xn, sm.eps, c->stream, next_dir(c)); }
-    run_gemm(c, P_GEMM_FC1, xn, L.w1, L.b1, M, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid, nullptr, nullptr,
-             ZK_INTER, 1 << 30, next_dir(c));
-    run_gemm(c, P_GEMM_FC2, mid, L.w2, L.b2, M, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
-             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c));
+    if (int grc = run_gemm(c, P_GEMM_FC1, xn, L.w1, L.b1, M, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid, nullptr, nullptr,
+             ZK_INTER, 1 << 30, next_dir(c))) return grc;
+    if (int grc = run_gemm(c, P_GEMM_FC2, mid, L.w2, L.b2, M, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
+             zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c))) return grc;
     if (c->tap_layer == l) {
       HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
       HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -496,7 +512,6 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
 int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d_idx, int B, float* d_logits) {
   StageModel& sm = c->model[stage];
   const bool sp = sm.mode != ZK_F16;
-  const int lf = (sm.mode == ZK_F16C8) ? ZK_LO_C8 : ZK_LO_F16;
   // micro_batch == 0 (auto).  Large batches: as few, equal micro-batches of at most 512 windows as possible (≈ 21 GB of
   // activations; every GEMM then runs >= 12 rounds of the 256 persistent workgroups and the per-launch tails and
   // the ragged last micro-batch stop mattering: 1024 windows as 2 x 512 measured +3 % over 9 x 107 + 61).  Small
@@ -523,11 +538,11 @@ int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d
     {
       ProfScope ps(c, P_EMBED);
       if (src_full)
-        zk_launch_im2col_full(src_full + (size_t)b0 * ZK_MAXLEN * ZK_NMEL, nb, c->patchA.get(sp, lf), c->stream);
+        zk_launch_im2col_full(src_full + (size_t)b0 * ZK_MAXLEN * ZK_NMEL, nb, c->patchA.get(sp, patch_lo_fmt(sm.mode)), c->stream);
       else
         zk_launch_im2col_compact(c->feat.as<float>() + (d_idx ? 0 : (size_t)b0 * c->feat_frames * ZK_NMEL),
                                  c->feat_frames, d_idx ? d_idx + b0 : nullptr, nb, sm.mean, sm.std * 2.0f,
-                                 c->patchA.get(sp, lf), c->stream);
+                                 c->patchA.get(sp, patch_lo_fmt(sm.mode)), c->stream);
     }
     if (tapped) c->tap_layer = -2;  // tap only the first micro-batch
     rc = forward_micro(c, sm, nb, d_logits + (size_t)b0 * sm.num_labels);
@@ -1083,22 +1098,62 @@ int zk_debug_get_tap(zk_ctx* c, float* out, int32_t n_windows) {
 }
 
 // ---- test hooks: run ONE kernel on caller-provided fp32 host data (tests/test_kernels_gpu.py) -------------------------
+// ZK_TEST_TILED_IN / ZK_TEST_TILED_OUT (ORed into `epi` of zk_test_gemm / `nsplit` of zk_test_layernorm, zk_test_attention):
+// the kernel reads its x planes / writes its output planes in the k-slice-major tile form (zk_planes::tiled) that the
+// ZK_F16C8 forward uses between its GEMM-side kernels; the hook converts on the host, with the formula of zk_common.h
+// written out independently, so that tests can demand tiled == row-major bit for bit.
+}      // extern "C"
+namespace {
+size_t host_tiled_off(size_t m, size_t k, size_t K) {
+  return (((m >> 8) * (K >> 6) + (k >> 6)) * 256 + (m & 255)) * 64 + ((((k & 63) >> 3) ^ ((m >> 1) & 7)) << 3) + (k & 7);
+}
+// device plane [rows_pad, K] (16-bit elements), row-major <-> tiled, through the host
+int retile_plane(zk_ctx* c, half_t* d, size_t rows_pad, size_t K, bool to_tiled) {
+  std::vector<uint16_t> a(rows_pad * K), b(rows_pad * K);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(a.data(), d, a.size() * 2, hipMemcpyDeviceToHost));
+  for (size_t m = 0; m < rows_pad; ++m)
+    for (size_t k = 0; k < K; ++k) {
+      const size_t t = host_tiled_off(m, k, K), r = m * K + k;
+      if (to_tiled) b[t] = a[r]; else b[r] = a[t];
+    }
+  HIPCHK(c, hipMemcpy(d, b.data(), b.size() * 2, hipMemcpyHostToDevice));
+  return ZK_OK;
+}
+}      // namespace
+extern "C" {
+
 int zk_test_layernorm(zk_ctx* c, const float* x, const float* gamma, const float* beta, int32_t rows, float eps,
-                      int32_t nsplit, float* out) {
+                      int32_t nsplit_flags, float* out) {
   if (!c) return ZK_E_ARG;
+  const int32_t nsplit = nsplit_flags & 0xFF;
+  const bool tiled_out = (nsplit_flags & ZK_TEST_TILED_OUT) != 0;
+  if (tiled_out && nsplit != ZK_F16C8) return fail(c, ZK_E_ARG, "tiled planes exist in ZK_F16C8 only");
   HIPCHK(c, hipSetDevice(c->device));
   DevArena mem(c->stream);
-  const size_t n = (size_t)rows * ZK_HIDDEN;
+  const size_t rows_pad = ((size_t)rows + 255) / 256 * 256;
+  const size_t n = (size_t)rows * ZK_HIDDEN, np = rows_pad * ZK_HIDDEN;
   float *dx, *dg, *db; half_t *hi, *lo; int32_t* dexp;
   HIPCHK(c, mem.alloc(&dx, n * 4)); HIPCHK(c, mem.alloc(&dg, ZK_HIDDEN * 4)); HIPCHK(c, mem.alloc(&db, ZK_HIDDEN * 4));
-  HIPCHK(c, mem.alloc(&hi, n * 2)); HIPCHK(c, mem.alloc(&lo, n * 2));
+  HIPCHK(c, mem.alloc(&hi, np * 2)); HIPCHK(c, mem.alloc(&lo, np * 2));
+  HIPCHK(c, hipMemsetAsync(hi, 0, np * 2, c->stream)); HIPCHK(c, hipMemsetAsync(lo, 0, np * 2, c->stream));
   HIPCHK(c, mem.alloc(&dexp, (size_t)rows * 4)); HIPCHK(c, hipMemsetAsync(dexp, 0, (size_t)rows * 4, c->stream));
   HIPCHK(c, hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dg, gamma, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(db, beta, ZK_HIDDEN * 4, hipMemcpyHostToDevice));
   const int lf = nsplit == ZK_F16C8 ? ZK_LO_C8 : ZK_LO_F16;
-  zk_launch_layernorm(dx, ZK_HIDDEN, dg, db, rows, zk_planes{hi, nsplit != ZK_F16 ? lo : nullptr, lf, dexp}, eps, c->stream);
+  {
+    zk_planes op{hi, nsplit != ZK_F16 ? lo : nullptr, lf, dexp};
+    op.tiled = tiled_out ? 1 : 0;
+    zk_launch_layernorm(dx, ZK_HIDDEN, dg, db, rows, op, eps, c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (tiled_out) {
+    int rc = retile_plane(c, hi, rows_pad, ZK_HIDDEN, false);
+    if (!rc) rc = retile_plane(c, lo, rows_pad, ZK_HIDDEN, false);
+    if (rc) return rc;
+  }
   std::vector<uint16_t> h(n), l(n, 0);
   std::vector<int32_t> ex(rows, 0);
   HIPCHK(c, hipMemcpy(h.data(), hi, n * 2, hipMemcpyDeviceToHost));
@@ -1123,8 +1178,13 @@ int zk_test_layernorm(zk_ctx* c, const float* x, const float* gamma, const float
 // x [M,K], w [N,K], bias [N] fp32 host.  epi STORE/GELU: out [M,N] = planes summed.  RESID: out [M,N] in/out.
 // PATCH: M must be a multiple of 1212, pos [1214,N], out [(M/1212)*1214, N] (rows 0,1 of each window untouched).
 int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, int32_t M, int32_t N, int32_t K,
-                 int32_t epi, int32_t nsplit, const float* pos, float* out) {
+                 int32_t epi_flags, int32_t nsplit, const float* pos, float* out) {
   if (!c) return ZK_E_ARG;
+  const int32_t epi = epi_flags & 0xFF;
+  const bool tiled_in = (epi_flags & ZK_TEST_TILED_IN) != 0, tiled_out = (epi_flags & ZK_TEST_TILED_OUT) != 0;
+  const int pad_byte = (epi_flags & ZK_TEST_POISON_PAD) ? 0x7E : 0;      // 0x7E7E = fp16 NaN; as e4m3 bytes: 448
+  if ((tiled_in || tiled_out) && nsplit != ZK_F16C8) return fail(c, ZK_E_ARG, "tiled planes exist in ZK_F16C8 only");
+  if (tiled_out && epi != ZK_EPI_GELU) return fail(c, ZK_E_ARG, "only the GELU epilogue writes tiled planes");
   if (N % 256 || K % 64 || M < 1) return fail(c, ZK_E_SHAPE, "zk_test_gemm: need N%%256==0, K%%64==0");
   if (epi == ZK_EPI_PATCH && (M % ZK_NPATCH || N != ZK_HIDDEN)) return fail(c, ZK_E_SHAPE, "PATCH epilogue: M%%1212==0, N==768");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1137,11 +1197,12 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   HIPCHK(c, mem.alloc(&dx, nx * 4)); HIPCHK(c, mem.alloc(&dw, nw * 4)); HIPCHK(c, mem.alloc(&dbias, (size_t)N * 4));
   // x planes are padded by one 256-row tile: the ZK_F16C8 kernel reads the last row block whole (zk_gemm_args: rows
   // M .. ceil(M/256)*256 must be readable; their products are never stored)
-  const size_t nxp = nx + (size_t)256 * K;
+  const size_t m_pad = ((size_t)M + 255) / 256 * 256;
+  const size_t nxp = m_pad * K;      // exactly the whole row blocks the launch contract asks for (zk_gemm_args::x_rows)
   HIPCHK(c, mem.alloc(&xh, nxp * 2)); HIPCHK(c, mem.alloc(&xl, nxp * 2));
   // (memsets go on the context's stream: a plain hipMemset runs on the NULL stream, which the non-blocking context stream
   // does not wait for — it could land after the kernels below had written the buffer)
-  HIPCHK(c, hipMemsetAsync(xh, 0, nxp * 2, c->stream)); HIPCHK(c, hipMemsetAsync(xl, 0, nxp * 2, c->stream));
+  HIPCHK(c, hipMemsetAsync(xh, pad_byte, nxp * 2, c->stream)); HIPCHK(c, hipMemsetAsync(xl, pad_byte, nxp * 2, c->stream));
   HIPCHK(c, mem.alloc(&wh, nw * 2)); HIPCHK(c, mem.alloc(&wl, nw * 2));
   HIPCHK(c, hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dw, w, nw * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice));
@@ -1159,18 +1220,31 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
     HIPCHK(c, hipMemcpy(dres, out, no * 4, hipMemcpyHostToDevice));
     if (epi == ZK_EPI_PATCH) { HIPCHK(c, mem.alloc(&dpos, (size_t)ZK_SEQ * N * 4)); HIPCHK(c, hipMemcpy(dpos, pos, (size_t)ZK_SEQ * N * 4, hipMemcpyHostToDevice)); }
   } else {
-    HIPCHK(c, mem.alloc(&oh, no * 2)); HIPCHK(c, mem.alloc(&ol, no * 2));
-    HIPCHK(c, hipMemsetAsync(ol, 0, no * 2, c->stream));
+    const size_t nop = tiled_out ? m_pad * N : no;      // tiled planes hold whole row blocks
+    HIPCHK(c, mem.alloc(&oh, nop * 2)); HIPCHK(c, mem.alloc(&ol, nop * 2));
+    HIPCHK(c, hipMemsetAsync(oh, 0, nop * 2, c->stream)); HIPCHK(c, hipMemsetAsync(ol, 0, nop * 2, c->stream));
+  }
+  if (tiled_in) {
+    int rc = retile_plane(c, xh, m_pad, K, true);
+    if (!rc) rc = retile_plane(c, xl, m_pad, K, true);
+    if (rc) return rc;
   }
   zk_gemm_args a;
   a.x_hi = xh; a.x_lo = nsplit != ZK_F16 ? xl : nullptr; a.w_hi = wh; a.w_lo = nsplit != ZK_F16 ? wl : nullptr; a.bias = dbias;
   a.x_rowexp = dexp;
   a.M = M; a.N = N; a.K = K; a.o_hi = oh; a.o_lo = nsplit != ZK_F16 ? ol : nullptr; a.resid = dres; a.pos = dpos; a.lo_n_limit = N; a.lo_c8_from = 1 << 30;
   a.w_exp = w_exp;
-  if (nsplit == ZK_F16C8) zk_launch_gemm_c8(a, epi, c->stream);
-  else zk_launch_gemm(a, epi, nsplit, c->stream);
+  a.x_rows = (int64_t)m_pad; a.x_tiled = tiled_in; a.o_tiled = tiled_out;
+  if (nsplit == ZK_F16C8) {
+    if (zk_launch_gemm_c8(a, epi, c->stream)) return fail(c, ZK_E_SHAPE, "zk_launch_gemm_c8 refused the launch");
+  } else zk_launch_gemm(a, epi, nsplit, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (tiled_out) {
+    int rc = retile_plane(c, oh, m_pad, N, false);
+    if (!rc) rc = retile_plane(c, ol, m_pad, N, false);
+    if (rc) return rc;
+  }
   if (dres) HIPCHK(c, hipMemcpy(out, dres, no * 4, hipMemcpyDeviceToHost));
   else {
     std::vector<uint16_t> h(no), l(no);
@@ -1188,24 +1262,37 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
 }
 
 // qkv fp32 host [W*1214, 2304] -> out fp32 host [W*1214, 768]
-int zk_test_attention(zk_ctx* c, const float* qkv, int32_t W, int32_t nsplit, float* out) {
+int zk_test_attention(zk_ctx* c, const float* qkv, int32_t W, int32_t nsplit_flags, float* out) {
   if (!c) return ZK_E_ARG;
+  const int32_t nsplit = nsplit_flags & 0xFF;
+  const bool tiled_out = (nsplit_flags & ZK_TEST_TILED_OUT) != 0;
+  if (tiled_out && nsplit != ZK_F16C8) return fail(c, ZK_E_ARG, "tiled planes exist in ZK_F16C8 only");
   HIPCHK(c, hipSetDevice(c->device));
   DevArena mem(c->stream);
   const size_t rows = (size_t)W * ZK_SEQ, nq = rows * 3 * ZK_HIDDEN, no = rows * ZK_HIDDEN;
+  const size_t rows_pad = (rows + 255) / 256 * 256, nop = rows_pad * ZK_HIDDEN;
   float* dq; half_t *qh, *ql, *oh, *ol;
   HIPCHK(c, mem.alloc(&dq, nq * 4)); HIPCHK(c, mem.alloc(&qh, nq * 2)); HIPCHK(c, mem.alloc(&ql, nq * 2));
-  HIPCHK(c, mem.alloc(&oh, no * 2)); HIPCHK(c, mem.alloc(&ol, no * 2));
-  HIPCHK(c, hipMemsetAsync(ol, 0, no * 2, c->stream));
+  HIPCHK(c, mem.alloc(&oh, nop * 2)); HIPCHK(c, mem.alloc(&ol, nop * 2));
+  HIPCHK(c, hipMemsetAsync(oh, 0, nop * 2, c->stream)); HIPCHK(c, hipMemsetAsync(ol, 0, nop * 2, c->stream));
   HIPCHK(c, hipMemcpy(dq, qkv, nq * 4, hipMemcpyHostToDevice));
   zk_launch_split_f32(dq, (int64_t)nq, 1.f, qh, ql, c->stream);
   const int lf = nsplit == ZK_F16C8 ? ZK_LO_C8 : ZK_LO_F16;
   if (nsplit == ZK_F16C8)      // as the fused QKV epilogue of this mode leaves them: k's lo entries are c8 byte pairs
     zk_launch_split_c8_cols(dq, (int)rows, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_HIDDEN, ql, c->stream);
-  zk_launch_attention(zk_planes{qh, nsplit != ZK_F16 ? ql : nullptr, ZK_LO_F16}, zk_planes{oh, nsplit != ZK_F16 ? ol : nullptr, lf}, W,
-                      nsplit == ZK_F16C8 ? 2 : (nsplit != ZK_F16 ? 3 : 1), 0, c->stream);
+  {
+    zk_planes op{oh, nsplit != ZK_F16 ? ol : nullptr, lf};
+    op.tiled = tiled_out ? 1 : 0;
+    zk_launch_attention(zk_planes{qh, nsplit != ZK_F16 ? ql : nullptr, ZK_LO_F16}, op, W,
+                        nsplit == ZK_F16C8 ? 2 : (nsplit != ZK_F16 ? 3 : 1), 0, c->stream);
+  }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (tiled_out) {
+    int rc = retile_plane(c, oh, rows_pad, ZK_HIDDEN, false);
+    if (!rc) rc = retile_plane(c, ol, rows_pad, ZK_HIDDEN, false);
+    if (rc) return rc;
+  }
   std::vector<uint16_t> h(no), l(no);
   HIPCHK(c, hipMemcpy(h.data(), oh, no * 2, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(l.data(), ol, no * 2, hipMemcpyDeviceToHost));

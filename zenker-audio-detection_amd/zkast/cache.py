@@ -157,9 +157,16 @@ class CompactFeatures:
         head = dict(magic=_COMPACT_MAGIC, shape=list(self.logmel.shape), metadata=metadata or {},
                     provenance=self.provenance)
         tmp = path + ".part"
-        with open(tmp, "wb") as f:
-            np.savez(f, header=np.frombuffer(json.dumps(head).encode("utf-8"), np.uint8), logmel=self.logmel)
-        os.replace(tmp, path)          # readers never see a half-written store
+        try:
+            with open(tmp, "wb") as f:
+                np.savez(f, header=np.frombuffer(json.dumps(head).encode("utf-8"), np.uint8), logmel=self.logmel)
+            os.replace(tmp, path)      # readers never see a half-written store
+        except BaseException:
+            try:                       # a failed write (disk full, interrupt) leaves no stray .part file behind
+                os.unlink(tmp)
+            except OSError:
+                pass
+            raise
 
     @classmethod
     def load(cls, path: str):
@@ -233,16 +240,30 @@ class FeatureCache:
         return feats, meta
 
     def store(self, key: EntryKey, feats: CompactFeatures, fx, tag: str = "stage1") -> None:
+        """Best effort, like the reference (…_cache.py:181-192 catches Exception and carries on): a read-only or full cache
+        directory, a failing torch.save (RuntimeError) or the (N,1024,128) expansion of the `.pt` twin running out of memory
+        (MemoryError; 512 KiB per window) must not stop the patient's inference.  The two files are written independently:
+        a failing twin does not take the compact store with it."""
         meta = key.metadata(len(feats))
         compact_path, bundle_path = self._paths(key)
         try:
             feats.save(compact_path, meta)
             self.log(f"[cache:{tag}] Saved {compact_path}")
-            if self.write_reference_bundle:
-                write_reference_bundle(bundle_path, feats.expand(fx), meta)
-                self.log(f"[cache:{tag}] Saved {bundle_path}")
-        except OSError as exc:            # a read-only or full cache directory must not stop the inference
-            self.log(f"[cache:{tag}] could not write the cache entry: {exc}")
+        except Exception as exc:          # noqa: BLE001
+            self.log(f"[cache:{tag}] could not write {compact_path}: {type(exc).__name__}: {exc}")
+        if not self.write_reference_bundle:
+            return
+        tmp = bundle_path + ".part"
+        try:
+            write_reference_bundle(tmp, feats.expand(fx), meta)
+            os.replace(tmp, bundle_path)
+            self.log(f"[cache:{tag}] Saved {bundle_path}")
+        except Exception as exc:          # noqa: BLE001
+            self.log(f"[cache:{tag}] could not write {bundle_path}: {type(exc).__name__}: {exc}")
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
 
 
 def write_reference_bundle(path: str, expanded: np.ndarray, base_metadata: Dict[str, Any]) -> None:

@@ -21,6 +21,7 @@ CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 ZK_F16, ZK_F16C8, ZK_F16X3 = 1, 2, 3
 ZK_DT_F32, ZK_DT_F16, ZK_DT_BF16 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_PATCH = 0, 1, 2, 3
+TEST_TILED_IN, TEST_TILED_OUT, TEST_POISON_PAD = 0x100, 0x200, 0x400      # include/zkast.h: ZK_TEST_*
 COMPUTE_MODES = {"f16": ZK_F16, "f16c8": ZK_F16C8, "f16x3": ZK_F16X3, 1: ZK_F16, 2: ZK_F16C8, 3: ZK_F16X3}
 
 # every symbol include/zkast.h declares (tests/test_abi.py checks the .so exports exactly these)
@@ -491,15 +492,16 @@ class Context:
         return out
 
     # ---- single-kernel test hooks ----
-    def test_layernorm(self, x, gamma, beta, eps, nsplit):
+    def test_layernorm(self, x, gamma, beta, eps, nsplit, tiled=False):
         x = np.ascontiguousarray(x, np.float32)
         out = np.empty_like(x)
         self._chk(self.lib.zk_test_layernorm(self.h, x.ctypes.data, np.ascontiguousarray(gamma, np.float32).ctypes.data,
                                              np.ascontiguousarray(beta, np.float32).ctypes.data, x.shape[0], float(eps),
-                                             int(nsplit), out.ctypes.data), "zk_test_layernorm")
+                                             int(nsplit) | (TEST_TILED_OUT if tiled else 0), out.ctypes.data),
+                  "zk_test_layernorm")
         return out
 
-    def test_gemm(self, x, w, bias, epi, nsplit, resid=None, pos=None):
+    def test_gemm(self, x, w, bias, epi, nsplit, resid=None, pos=None, tiled_in=False, tiled_out=False, poison_pad=False):
         x = np.ascontiguousarray(x, np.float32)
         w = np.ascontiguousarray(w, np.float32)
         bias = np.ascontiguousarray(bias, np.float32)
@@ -512,7 +514,9 @@ class Context:
             out = np.ascontiguousarray(resid, np.float32).copy()
         else:
             out = np.empty((M, N), np.float32)
-        self._chk(self.lib.zk_test_gemm(self.h, x.ctypes.data, w.ctypes.data, bias.ctypes.data, M, N, K, int(epi),
+        flags = (int(epi) | (TEST_TILED_IN if tiled_in else 0) | (TEST_TILED_OUT if tiled_out else 0)
+                 | (TEST_POISON_PAD if poison_pad else 0))
+        self._chk(self.lib.zk_test_gemm(self.h, x.ctypes.data, w.ctypes.data, bias.ctypes.data, M, N, K, flags,
                                         int(nsplit), None if pos is None else pos.ctypes.data, out.ctypes.data),
                   "zk_test_gemm")
         return out
@@ -524,10 +528,11 @@ class Context:
                                             out.ctypes.data), "zk_test_split_c8")
         return out
 
-    def test_attention(self, qkv, n_windows, nsplit):
+    def test_attention(self, qkv, n_windows, nsplit, tiled=False):
         qkv = np.ascontiguousarray(qkv, np.float32)
         out = np.empty((qkv.shape[0], 768), np.float32)
-        self._chk(self.lib.zk_test_attention(self.h, qkv.ctypes.data, int(n_windows), int(nsplit), out.ctypes.data),
+        self._chk(self.lib.zk_test_attention(self.h, qkv.ctypes.data, int(n_windows),
+                                             int(nsplit) | (TEST_TILED_OUT if tiled else 0), out.ctypes.data),
                   "zk_test_attention")
         return out
 

@@ -106,15 +106,15 @@ def window_geometry(n_samples: int, window_sec: float, hop_sec: float, sr: int =
 
 def window_audio(audio: np.ndarray, window_sec: float, hop_sec: float, sr: int = SAMPLING_RATE) -> List[np.ndarray]:
     """The window list of the reference's window_audio (:62-75) for callers that want it materialised (the product path
-    never does: the kernels cut windows out of the recording by index).  Full windows are zero-copy strided views of
-    `audio`; a recording shorter than one window gives its single zero-padded window."""
+    never does: the kernels cut windows out of the recording by index).  Full windows are zero-copy slices of `audio`
+    (they alias the recording and, at hop < window, each other — exactly like the reference's); a recording shorter than
+    one window gives its single zero-padded window."""
     n, win, _hop = window_geometry(len(audio), window_sec, hop_sec, sr)
     if len(audio) < win:
         only = np.zeros(win, dtype=audio.dtype)
         only[: len(audio)] = audio
         return [only]
-    grid = np.lib.stride_tricks.sliding_window_view(audio, win)[::_hop]
-    return [grid[i] for i in range(n)]
+    return [audio[i * _hop: i * _hop + win] for i in range(n)]      # plain slices, as the reference's: writable iff `audio` is
 
 
 # ----------------- Model loading -----------------
@@ -161,12 +161,43 @@ def forward_probs_recording(model, fx, audio: np.ndarray, window_sec: float, hop
 
 
 # ----------------- File discovery -----------------
+def wav_header(path: str):
+    """(format_tag, channels, sample_rate, bits, data_bytes) from the RIFF chunk HEADERS alone: chunk bodies are skipped
+    with seek(), so a 30-minute recording costs a few dozen bytes of I/O (torchaudio.info, :133)."""
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            raise ValueError(f"{path}: not a RIFF/WAVE file")
+        fmt = data_bytes = None
+        end = os.fstat(f.fileno()).st_size
+        while True:
+            ck = f.read(8)
+            if len(ck) < 8:
+                break
+            cid, size = ck[:4], struct.unpack("<I", ck[4:])[0]
+            body_at = f.tell()
+            if cid == b"fmt ":
+                body = f.read(min(size, 40))
+                tag, ch, sr, _br, _ba, bits = struct.unpack("<HHIIHH", body[:16])
+                if tag == 0xFFFE and len(body) >= 26:
+                    tag = struct.unpack("<H", body[24:26])[0]
+                fmt = (tag, ch, sr, bits)
+            elif cid == b"data":
+                data_bytes = max(0, min(size, end - body_at))      # a truncated file holds what it holds
+            f.seek(body_at + size + (size & 1))
+    if fmt is None or data_bytes is None:
+        raise ValueError(f"{path}: missing fmt/data chunk")
+    return (*fmt, data_bytes)
+
+
 def _wav_num_frames(path: str) -> int:
-    """Frames of a WAV file from its header alone (0 when unreadable)."""
+    """Frames of a WAV file from its header alone (0 when unreadable or when the header describes no samples: zero
+    channels / zero bits must count as an empty recording, not raise out of discover_two_files)."""
     try:
-        _tag, ch, _sr, bits, raw = parse_wav(path)
-        return len(raw) // (ch * (bits // 8))
-    except (OSError, ValueError, struct.error):
+        _tag, ch, _sr, bits, nbytes = wav_header(path)
+        frame = ch * (bits // 8)
+        return nbytes // frame if frame > 0 else 0
+    except (OSError, ValueError, ArithmeticError, struct.error):
         return 0
 
 
@@ -287,16 +318,44 @@ def _decide(ctx, s1_logits, swallow_indices, s2_logits, stage1_threshold, stage2
     return summary, s1_probs, s1_preds, stage2_aligned_classes, stage2_results
 
 
-def _cached_features(path: str, ctx, fx, window_sec: float, hop_sec: float, cache_dir: str, refresh: bool, log=print):
-    """Compact log-mel of the recording in the context's audio slot, through `zkast.cache.FeatureCache`: a store (or a
-    reference `.pt` bundle) of this file / window grid / extractor is used when present, otherwise the device computes
-    the log-mel and the entry is written (compact store + reference-format twin)."""
+def _extractors_differ_only_in_stats(fx_a, fx_b) -> bool:
+    """One compact store serves both stages only when the two extractors differ in nothing but mean / std (each stage
+    re-normalises the same un-normalised log-mel: an affine map).  The reference re-uses stage-1 features only for EQUAL
+    extractors (..._cache.py:418-422) and otherwise extracts stage 2 on its own; a difference in num_mel_bins, max_length,
+    do_normalize, sampling_rate ... must therefore not be papered over."""
+    da, db = dict(fx_a.to_dict()), dict(fx_b.to_dict())
+    for d in (da, db):
+        d.pop("mean", None), d.pop("std", None)
+    return da == db
+
+
+def _length_after_resampling(n_frames: int, sr: int, target_sr: int = SAMPLING_RATE) -> int:
+    """samples zk_audio_load leaves in the audio slot: ceil(new * n / orig) with the rates reduced by their gcd"""
+    if sr == target_sr:
+        return n_frames
+    g = int(np.gcd(sr, target_sr))
+    orig, new = sr // g, target_sr // g
+    return (new * n_frames + orig - 1) // orig
+
+
+def _cached_features(path: str, ctx, fx, window_sec: float, hop_sec: float, cache_dir: str, refresh: bool, log=print,
+                     device: int = 0):
+    """Compact log-mel of the recording `path`, through `zkast.cache.FeatureCache`: a store (or a reference `.pt` bundle)
+    of this file / window grid / extractor is used when present — the window count then comes from the WAV HEADER and the
+    recording is neither decoded nor uploaded; otherwise the file goes to the device once, the device computes the
+    log-mel and the entry is written (compact store + reference-format twin)."""
     from . import cache as _cache
-    n, win, hop = window_geometry(ctx.audio_len(), window_sec, hop_sec)
+    _tag, ch, sr, bits, nbytes = wav_header(path)
+    frame = ch * (bits // 8)
+    n_samples = _length_after_resampling(nbytes // frame if frame > 0 else 0, sr)
+    n, win, hop = window_geometry(n_samples, window_sec, hop_sec)
     fc = _cache.FeatureCache(cache_dir, log=log)
     key = _cache.EntryKey.of(path, window_sec, hop_sec, SAMPLING_RATE, _cache.get_fx_fingerprint(fx))
     store = None if refresh else fc.lookup(key, n, fx)
     if store is None:
+        got = load_audio_to_device(path, device=device)
+        if got != n_samples:      # (header and decoder disagree: trust the decoder's length for the window grid)
+            n, win, hop = window_geometry(got, window_sec, hop_sec)
         ctx.logmel(None, 0, 0, hop, win, n)
         store = _cache.CompactFeatures.from_device(ctx, extractor="zk_logmel")
         fc.store(key, store, fx)
@@ -330,17 +389,23 @@ def run_patient(files: List[str], model_s1, fx_s1, model_s2, fx_s2, args_like: D
     decide = (args_like.get("stage1_threshold", 0.5), args_like.get("stage2_threshold", 0.5),
               args_like.get("stage1_forward_min_prob"), args_like.get("stage2_argmax", False))
     cache_dir = None if args_like.get("disable_cache") else args_like.get("feature_cache_dir")
+    log = args_like.get("log", print)
+    device = getattr(model_s1, "_device", 0)
+    if cache_dir and audios is None and not _extractors_differ_only_in_stats(fx_s1, fx_s2):
+        log("[cache] the two stages' extractors differ in more than mean / std: one feature store cannot serve both; "
+            "running without the feature cache")
+        cache_dir = None
     for idx, path in enumerate(files):
-        if audios is not None:
-            audio = audios[idx]
-        else:      # file -> device once; decode, resample, log-mel and both forwards read it there
-            load_audio_to_device(path, device=getattr(model_s1, "_device", 0))
-            audio = None
         if cache_dir and audios is None:      # the cached variant's options (..._cache.py:361-375): features via the cache
             store = _cached_features(path, model_s1._ctx, fx_s1, window_sec, hop_sec, cache_dir,
-                                     bool(args_like.get("refresh_cache")), args_like.get("log", print))
+                                     bool(args_like.get("refresh_cache")), log, device)
             summary, *_ = classify_features(store, model_s1, fx_s1, model_s2, fx_s2, *decide)
         else:
+            if audios is not None:
+                audio = audios[idx]
+            else:      # file -> device once; decode, resample, log-mel and both forwards read it there
+                load_audio_to_device(path, device=device)
+                audio = None
             summary, *_ = classify_recording(audio, model_s1, fx_s1, model_s2, fx_s2, window_sec, hop_sec, *decide)
         per_file[f"file_{idx}"] = {"path": path, **summary}
     return {
