@@ -1,6 +1,7 @@
 """Interleaved timing of several builds of the attention kernel (probe libraries from tools/build_variant.sh ... attention):
 every round visits every build once, median over rounds.
 usage: python tools/attn_ab_multi.py <windows> <rounds> <name>[,<name>...]   (name "base" = libzkast_probes.so)"""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); from _hip import cdll as _hip_cdll
 import ctypes as C
 import os
 import statistics
@@ -11,7 +12,7 @@ ZK = os.path.join(ROOT, "zenker-audio-detection_amd", "zkast")
 
 
 def load(name):
-    lib = C.CDLL(os.path.join(ZK, "libzkast_probes.so" if name in ("", "base") else f"libzkast_probes_{name}.so"))
+    lib = _hip_cdll(os.path.join(ZK, "libzkast_probes.so" if name in ("", "base") else f"libzkast_probes_{name}.so"))
     lib.zkp_bench_attention.restype = C.c_int
     lib.zkp_bench_attention.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_float)]
     return lib

@@ -1,8 +1,9 @@
 """Fill-path probe: the ZK_F16C8 GEMM's LDS-DMA stream alone (libzkast_probes.so), TB/s and GB/s per CU.
 usage: python tools/fill_probe.py [windows=512]"""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); from _hip import cdll as _hip_cdll
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("ZKAST_PROBES", os.path.join(ROOT, "zenker-audio-detection_amd", "zkast", "libzkast_probes.so")))
+lib = _hip_cdll(os.environ.get("ZKAST_PROBES", os.path.join(ROOT, "zenker-audio-detection_amd", "zkast", "libzkast_probes.so")))
 lib.zkp_fill_probe.restype = C.c_int
 lib.zkp_fill_probe.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_float)]
 M = (int(sys.argv[1]) if len(sys.argv) > 1 else 512) * 1214

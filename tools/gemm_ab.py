@@ -1,12 +1,13 @@
 """A/B timing of the ZK_F16C8 GEMM variants on the production shapes, device-resident random operands, interleaved
 rounds in ONE process (libzkast_probes.so: `ZK_PROBES=1 csrc/build.sh`), plus a bit-exact comparison of the outputs.
 usage: python tools/gemm_ab.py [windows=512] [variants=3] [iters=4] [rounds=5]"""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); from _hip import cdll as _hip_cdll
 import ctypes as C
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("ZKAST_PROBES", os.path.join(ROOT, "zenker-audio-detection_amd", "zkast", "libzkast_probes.so")))
+lib = _hip_cdll(os.environ.get("ZKAST_PROBES", os.path.join(ROOT, "zenker-audio-detection_amd", "zkast", "libzkast_probes.so")))
 lib.zkp_bench_gemm_c8.restype = C.c_int
 lib.zkp_bench_gemm_c8.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_float), C.POINTER(C.c_ulonglong)]
 

@@ -4,6 +4,7 @@ device-resident operands, median over rounds.  The first build is the reference 
 also compared dword for dword against the frozen round-1 kernel inside its own probe library.
 usage: python tools/gemm_ab_multi.py <windows> <rounds> <name>[,<name>...]     (name "" or "base" = libzkast_probes.so)
 env AB_ONLY=qkv,fc1,o,fc2   AB_ITERS=4   AB_CHECK=0 (skip the bit comparison)"""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); from _hip import cdll as _hip_cdll
 import ctypes as C
 import os
 import statistics
@@ -15,7 +16,7 @@ ZK = os.path.join(ROOT, "zenker-audio-detection_amd", "zkast")
 
 def load(name):
     path = os.path.join(ZK, "libzkast_probes.so" if name in ("", "base") else f"libzkast_probes_{name}.so")
-    lib = C.CDLL(path)
+    lib = _hip_cdll(path)
     lib.zkp_bench_gemm_c8.restype = C.c_int
     lib.zkp_bench_gemm_c8.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_float), C.POINTER(C.c_ulonglong)]
     return lib

@@ -1,12 +1,13 @@
 """A/B of the production ZK_F16C8 GEMM against the MX-fp6 correction-plane variant (csrc/gemm_c6.hip, probes library only)
 on the production shapes: ms per launch, algorithmic TFLOP/s, and how far the two outputs are apart.
 usage: python tools/gemm_c6_ab.py [windows=512] [iters=4] [rounds=3]"""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); from _hip import cdll as _hip_cdll
 import ctypes as C
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("ZKAST_PROBES", os.path.join(ROOT, "zenker-audio-detection_amd", "zkast", "libzkast_probes.so")))
+lib = _hip_cdll(os.environ.get("ZKAST_PROBES", os.path.join(ROOT, "zenker-audio-detection_amd", "zkast", "libzkast_probes.so")))
 lib.zkp_bench_gemm_c6.restype = C.c_int
 lib.zkp_bench_gemm_c6.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_float), C.POINTER(C.c_float)]
 windows = int(sys.argv[1]) if len(sys.argv) > 1 else 512

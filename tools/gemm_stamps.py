@@ -5,6 +5,7 @@ landed (vmcnt(0)), C = step barrier released.  Prints, per build / shape / step 
 over the last 64 steps of every (workgroup, wave); steps that carry a tile epilogue (> 1.6 x the median step) are left out.
 Also prints the clock the chip held during the launch (s_memtime against the 100 MHz s_memrealtime, per workgroup).
 usage: python tools/gemm_stamps.py <windows> <name>[,<name>...]      (libzkast_probes_<name>.so)"""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); from _hip import cdll as _hip_cdll
 import ctypes as C
 import os
 import sys
@@ -20,8 +21,9 @@ def main():
     names = sys.argv[2].split(",")
     M = windows * 1214
     shapes = [("qkv", 2304, 768, 0), ("fc1", 3072, 768, 1), ("o", 768, 768, 2), ("fc2", 768, 3072, 2)]
+    clocks = {}
     for n in names:
-        lib = C.CDLL(os.path.join(ZK, f"libzkast_probes_{n}.so"))
+        lib = _hip_cdll(os.path.join(ZK, f"libzkast_probes_{n}.so"))
         lib.zkp_bench_gemm_c8.restype = C.c_int
         lib.zkp_bench_gemm_c8.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_float), C.POINTER(C.c_ulonglong)]
         lib.zkp_c8_stamps_read.restype = C.c_int
@@ -54,6 +56,7 @@ def main():
                         sel = ok & (kind == k)
                         if sel.any():
                             rows.setdefault((k, w // 4), []).append(np.stack([issue[sel], wait[sel], bar[sel], step[sel]], 1))
+            clocks.setdefault(n, {})["gemm_" + sname] = {"ghz": round(float(ghz), 3), "ms_per_launch": round(float(ms[1]), 3)}
             if not buf.any():      # -DZK_C8_STAMPS=2: clock stamps only
                 print(f"{n} {sname}: kernel {ms[1]:.3f} ms, in-kernel clock {ghz:.2f} GHz (no per-step stamps in this build)", flush=True)
                 continue
@@ -65,6 +68,17 @@ def main():
                 q = np.median(v, 0)
                 print(f"   {'fp16' if k == 0 else 'c8  '} step, waves {'0-3' if h == 0 else '4-7'}: issue {q[0]:6.0f}  wait {q[1]:5.0f}  "
                       f"barrier {q[2]:5.0f}  step {q[3]:6.0f}   ({len(v)} steps)", flush=True)
+    out = os.environ.get("CLOCK_JSON")
+    if out:      # profiles/r04_gemm_clock.json: what bench.py quotes as roofline.in_kernel_clock_ghz
+        import hashlib
+        import json
+        first = names[0]
+        so = os.path.join(ZK, "libzkast.so")
+        json.dump({"note": f"tools/gemm_stamps.py {windows} {first}: probe build -DZK_C8_STAMPS=2 (s_memtime / s_memrealtime pair at kernel "
+                           "entry and exit, the k-loop runs as shipped), 80 back-to-back launches per shape on random operands, "
+                           "median over the 256 workgroups; clock = d s_memtime / d s_memrealtime x 100 MHz",
+                   "windows": windows, "libzkast_sha256_at_measurement": hashlib.sha256(open(so, "rb").read()).hexdigest(),
+                   "kernels": clocks[first]}, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -230,6 +230,15 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
                                        4, 0, 0);
     }
   };
+#ifndef ZK_C8_BUFLDS
+#define ZK_C8_BUFLDS 0
+#endif
+#if ZK_C8_BUFLDS
+  const __amdgpu_buffer_rsrc_t rs_xh = __builtin_amdgcn_make_buffer_rsrc((void*)a.x_hi, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_xl = __builtin_amdgcn_make_buffer_rsrc((void*)a.x_lo, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_lo, 0, -1, 0x00020000);
+#endif
 #if ZK_C8_ROLES
   // loader-role piece p of 16: X pieces 0..7, W pieces 8..15; piece (q, h) = (p >> 1 & 3, p & 1) covers the 8-row unit
   // q·8 + lw + 4h of its operand (rows q·64 + h·32 + lw·8 + srow: the swizzle term (row >> 1) & 7 depends on lw, srow only)
@@ -241,6 +250,25 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
     const int k0 = l_k * BK;
     const int q = (p >> 1) & 3, h = p & 1, unit = q * 8 + (wave & 3) + 4 * h;
     const bool isw = p >= 8;
+#if ZK_C8_BUFLDS
+    // probe (round 4): the same pieces as `buffer_load_dwordx4 ... offen lds` — one resource per plane held in SGPRs for
+    // the whole kernel, the piece's position as a 32-bit scalar offset (no 64-bit pointer arithmetic, no v_readfirstlane
+    // pair per piece), the lane's part as the 32-bit vector offset
+    if (XT && !isw) {
+      unsigned l16;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(l16));
+      const unsigned so = ((unsigned)((l_m0 >> 8) * nk + l_k) << 15) + (unsigned)(unit * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(KIND ? rs_xl : rs_xh, (__attribute__((address_space(3))) void*)(base + unit * 1024), 16,
+                                               (int)l16, (int)so, 0, 0);
+    } else {
+      const int r0 = (isw ? l_n0 : l_m0) + q * 64 + h * 32;
+      const unsigned so = ((unsigned)r0 * (unsigned)a.K + (unsigned)k0) * 2u;
+      asm volatile("" : "+v"(poff));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isw ? (KIND ? rs_wl : rs_wh) : (KIND ? rs_xl : rs_xh),
+                                               (__attribute__((address_space(3))) void*)(base + (isw ? XBYTES : 0) + unit * 1024), 16,
+                                               (int)poff, (int)so, 0, 0);
+    }
+#else
     if (XT && !isw) {      // (p is a constant at every call site: no branch is emitted)
       unsigned l16;      // lane·16, read here instead of kept in a register across the k-loop
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(l16));
@@ -255,6 +283,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + poff),
                                      (__attribute__((address_space(3))) void*)(base + (isw ? XBYTES : 0) + unit * 1024), 16, 0, 0);
     }
+#endif
     if (KIND == 0 && p == 0) {
       unsigned l4;
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 2, %0" : "=v"(l4));
