@@ -70,6 +70,12 @@ int zk_synchronize(zk_ctx* ctx);
 /* exact last-layer pruning: only tokens 0/1 feed the head (ASTModel.forward:304), so the last layer's attention
  * queries, O projection and MLP run on those two rows per window only.  Default on; results are unchanged.       */
 int zk_set_prune_last_layer(zk_ctx* ctx, int enable);
+/* exact layer-0 constant-row reuse: a 1 s window fills 98 of the extractor's 1024 frames (feature_extraction_...py:143-151),
+ * so 1094 of its 1214 tokens (cls, distillation, the padding-only patches) enter layer 0 with values that do not depend
+ * on the window; their embedding rows and layer-0 LayerNorm + q|k|v rows are computed once per model and copied.  Applies
+ * to forwards from the feature slot (zk_logmel / zk_features_set / zk_two_stage), never to caller-provided
+ * input_values.  Default on; results are bit-identical.                                                            */
+int zk_set_layer0_reuse(zk_ctx* ctx, int enable);
 int zk_set_micro_batch(zk_ctx* ctx, int32_t windows); /* forward is chunked into micro-batches; 0 = auto (default)    */
 const char* zk_version(void);
 

@@ -281,6 +281,78 @@ def test_last_layer_pruning_is_exact():
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("mode", ["f16c8", "f16x3", "f16"])
+def test_layer0_constant_row_reuse_is_exact(mode):
+    """zk_set_layer0_reuse: 1094 of a 1 s window's 1214 tokens enter layer 0 with window-independent values; their
+    embedding, LayerNorm-1 and q|k|v rows come from a per-model table.  Everything downstream must be bit-identical to
+    computing them: the residual stream after the embeddings and after layers 0 and 5 (all 1214 rows), the logits, with a
+    window index list, across micro-batch splits, after a change of the extractor statistics or of the compute mode."""
+    from zkast import lib, synth
+    model, _ = _model(31, "sens", 0)
+    model.set_compute_mode(mode)
+    ctx = lib.get_context(0)
+    rec = synth.synth_recording(19, 16000 + 20 * 8000)
+    ctx.logmel(rec, rec.size, 0, 8000, 16000, 21)
+    idx = np.array([20, 3, 3, 11, 0], np.int32)
+
+    def run(reuse):
+        ctx.set_layer0_reuse(reuse)
+        out = {}
+        for layer in (-1, 0, 5):
+            ctx.debug_tap(layer)
+            out[("logits", layer)] = model.forward_from_slot(21)
+            out[("tap", layer)] = ctx.debug_get_tap(4)
+        ctx.debug_tap(-2)
+        out["gather"] = model.forward_from_slot(0, idx)
+        for mb in (1, 4, 21):
+            ctx.set_micro_batch(mb)
+            out[("mb", mb)] = model.forward_from_slot(21)
+        ctx.set_micro_batch(0)
+        return out
+
+    try:
+        off, on = run(False), run(True)
+        for k in off:
+            assert np.array_equal(off[k], on[k]), k
+        assert np.array_equal(on[("mb", 1)], on[("logits", 0)]) and np.array_equal(on["gather"], on[("logits", 0)][idx])
+        # another pad value (the table depends on the extractor's mean / std) and back
+        ctx.set_fx(0, -6.5, 2.75)
+        a = model.forward_from_slot(21)
+        ctx.set_layer0_reuse(False)
+        assert np.array_equal(a, model.forward_from_slot(21)) and not np.array_equal(a, on[("logits", 0)])
+        ctx.set_layer0_reuse(True)
+        ctx.set_fx(0, -1.1509622, 3.5340312)
+        assert np.array_equal(model.forward_from_slot(21), on[("logits", 0)])
+    finally:
+        ctx.set_layer0_reuse(True)
+        ctx.set_micro_batch(0)
+        ctx.debug_tap(-2)
+        model.set_compute_mode("f16c8")
+
+
+@pytest.mark.parametrize("window_sec,frames", [(0.5, 48), (2.0, 198), (1.03, 101), (10.3, 1024)])
+def test_layer0_reuse_follows_the_frame_count(window_sec, frames):
+    """other window lengths: ceil(frames / 10) real time patches (5, 20, 11); a window that fills all 1024 frames has no
+    constant patch rows and takes the ordinary path"""
+    from zkast import lib, synth
+    model, _ = _model(12, "init", 0)
+    ctx = lib.get_context(0)
+    win = int(window_sec * 16000)
+    rec = synth.synth_recording(35, win * 3)
+    ctx.logmel(rec, rec.size, 0, win, win, 3)
+    assert ctx.features_shape() == (3, frames)
+    try:
+        ctx.set_layer0_reuse(False)
+        ctx.debug_tap(0)
+        ref, ref_tap = model.forward_from_slot(3), ctx.debug_get_tap(3)
+        ctx.set_layer0_reuse(True)
+        got, got_tap = model.forward_from_slot(3), ctx.debug_get_tap(3)
+        assert np.array_equal(ref, got) and np.array_equal(ref_tap, got_tap)
+    finally:
+        ctx.set_layer0_reuse(True)
+        ctx.debug_tap(-2)
+
+
 def test_feature_cache_roundtrip_and_probs_from_features(tmp_path):
     """cached variant (..._cache.py:127-208): features computed once, stored as the reference's `.pt` bundle, re-loaded,
     and forward_probs_from_features on them equals forward_probs on the windows."""

@@ -17,15 +17,17 @@ namespace {
 template <bool COMPACT>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ src, int n_frames,
                                                      const int32_t* __restrict__ win_idx, int n_windows, float mean,
-                                                     float std2, half_t* __restrict__ o_hi, half_t* __restrict__ o_lo, int lo_fmt) {
+                                                     float std2, half_t* __restrict__ o_hi, half_t* __restrict__ o_lo, int lo_fmt,
+                                                     int t_real) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)n_windows * ZK_NPATCH * 32;
+  const int npr = t_real ? ZK_FOUT * t_real : ZK_NPATCH, tpf = t_real ? t_real : ZK_TOUT;      // rows per window, patches per f
+  const int64_t total = (int64_t)n_windows * npr * 32;
   if (gid >= total) return;
   const int seg = (int)(gid & 31);            // 32 segments of 8 per 256-wide row
-  const int64_t prow = gid >> 5;              // b*1212 + f*101 + t
-  const int b = (int)(prow / ZK_NPATCH);
-  const int p = (int)(prow - (int64_t)b * ZK_NPATCH);
-  const int f = p / ZK_TOUT, t = p - f * ZK_TOUT;
+  const int64_t prow = gid >> 5;              // b*npr + f*tpf + t
+  const int b = (int)(prow / npr);
+  const int p = (int)(prow - (int64_t)b * npr);
+  const int f = p / tpf, t = p - f * tpf;
   const int kf = seg >> 1, kt0 = (seg & 1) * 8;
   const int mel = f * ZK_FSTRIDE + kf;
   const int time0 = t * ZK_TSTRIDE + kt0;
@@ -83,6 +85,49 @@ __global__ __launch_bounds__(256) void gather_tok01_kernel(const half_t* __restr
   *(f4_t*)(h_out + dst) = *(const f4_t*)(hidden + src);
 }
 
+// ---- layer-0 constant-row reuse (zkast.hip: build_l0_table) ---------------------------------------------------------------
+// Of a window's 1214 token rows only the 12·t_real patch tokens with t < t_real see real frames (t_real = ceil(n_frames / 10)
+// = 10 for a 1 s window); cls, distillation and the other patch tokens have a layer-0 input that is the same for every
+// window.  Their residual rows and their layer-0 q|k|v rows come from a table, bit-identical to computing them.
+// one thread = 4 channels of one constant row
+__global__ __launch_bounds__(256) void l0_fill_hidden_kernel(float* __restrict__ hidden, const float* __restrict__ table,
+                                                             int n_windows, int t_real) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int tpad = ZK_TOUT - t_real, nconst = 2 + ZK_FOUT * tpad;
+  if (gid >= (int64_t)n_windows * nconst * (ZK_HIDDEN / 4)) return;
+  const int c4 = (int)(gid % (ZK_HIDDEN / 4));
+  const int64_t rr = gid / (ZK_HIDDEN / 4);
+  const int b = (int)(rr / nconst), i = (int)(rr - (int64_t)b * nconst);
+  int row = i;
+  if (i >= 2) { const int j = i - 2, f = j / tpad; row = 2 + f * ZK_TOUT + t_real + (j - f * tpad); }
+  *(f4_t*)(hidden + ((size_t)b * ZK_SEQ + row) * ZK_HIDDEN + c4 * 4) = *(const f4_t*)(table + (size_t)row * ZK_HIDDEN + c4 * 4);
+}
+
+// one thread = one 16-byte chunk of one token row, both planes
+__global__ __launch_bounds__(256) void l0_assemble_qkv_kernel(const half_t* __restrict__ r_hi, const half_t* __restrict__ r_lo,
+                                                              const half_t* __restrict__ t_hi, const half_t* __restrict__ t_lo,
+                                                              half_t* __restrict__ o_hi, half_t* __restrict__ o_lo, int n_windows,
+                                                              int t_real) {
+  constexpr int CH = 3 * ZK_HIDDEN / 8;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)n_windows * ZK_SEQ * CH) return;
+  const int ch = (int)(gid % CH);
+  const int64_t rr = gid / CH;
+  const int b = (int)(rr / ZK_SEQ), row = (int)(rr - (int64_t)b * ZK_SEQ);
+  const half_t *sh = t_hi + (size_t)row * (3 * ZK_HIDDEN), *sl = t_lo ? t_lo + (size_t)row * (3 * ZK_HIDDEN) : nullptr;
+  if (row >= 2) {
+    const int p = row - 2, f = p / ZK_TOUT, t = p - f * ZK_TOUT;
+    if (t < t_real) {
+      const size_t r = ((size_t)b * ZK_FOUT + f) * t_real + t;
+      sh = r_hi + r * (3 * ZK_HIDDEN);
+      sl = r_lo ? r_lo + r * (3 * ZK_HIDDEN) : nullptr;
+    }
+  }
+  const size_t oo = (size_t)rr * (3 * ZK_HIDDEN) + ch * 8;
+  *(h8_t*)(o_hi + oo) = *(const h8_t*)(sh + ch * 8);
+  if (o_lo) *(h8_t*)(o_lo + oo) = *(const h8_t*)(sl + ch * 8);
+}
+
 }  // namespace
 
 void zk_launch_gather_tok01(zk_planes att, const float* hidden, int n_windows, zk_planes att_out, float* hidden_out,
@@ -94,18 +139,32 @@ void zk_launch_gather_tok01(zk_planes att, const float* hidden, int n_windows, z
 }
 
 void zk_launch_im2col_compact(const float* feats, int n_frames, const int32_t* win_idx, int n_windows, float mean,
-                              float std2, zk_planes out, hipStream_t s) {
+                              float std2, zk_planes out, hipStream_t s, int t_real) {
   if (n_windows <= 0) return;
-  const int64_t total = (int64_t)n_windows * ZK_NPATCH * 32;
+  const int64_t total = (int64_t)n_windows * (t_real ? ZK_FOUT * t_real : ZK_NPATCH) * 32;
   hipLaunchKernelGGL(im2col_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feats, n_frames,
-                     win_idx, n_windows, mean, std2, out.hi, out.lo, out.lo_fmt);
+                     win_idx, n_windows, mean, std2, out.hi, out.lo, out.lo_fmt, t_real);
+}
+
+void zk_launch_l0_fill_hidden(float* hidden, const float* table, int n_windows, int t_real, hipStream_t s) {
+  if (n_windows <= 0) return;
+  const int nconst = 2 + ZK_FOUT * (ZK_TOUT - t_real);
+  const int64_t total = (int64_t)n_windows * nconst * (ZK_HIDDEN / 4);
+  hipLaunchKernelGGL(l0_fill_hidden_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hidden, table, n_windows, t_real);
+}
+
+void zk_launch_l0_assemble_qkv(zk_planes real_rows, zk_planes table, zk_planes out, int n_windows, int t_real, hipStream_t s) {
+  if (n_windows <= 0) return;
+  const int64_t total = (int64_t)n_windows * ZK_SEQ * (3 * ZK_HIDDEN / 8);
+  hipLaunchKernelGGL(l0_assemble_qkv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, real_rows.hi, real_rows.lo,
+                     table.hi, table.lo, out.hi, out.lo, n_windows, t_real);
 }
 
 void zk_launch_im2col_full(const float* input_values, int n_windows, zk_planes out, hipStream_t s) {
   if (n_windows <= 0) return;
   const int64_t total = (int64_t)n_windows * ZK_NPATCH * 32;
   hipLaunchKernelGGL(im2col_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, input_values,
-                     ZK_MAXLEN, (const int32_t*)nullptr, n_windows, 0.f, 1.f, out.hi, out.lo, out.lo_fmt);
+                     ZK_MAXLEN, (const int32_t*)nullptr, n_windows, 0.f, 1.f, out.hi, out.lo, out.lo_fmt, 0);
 }
 
 void zk_launch_cls_rows(float* hidden, const float* cls, const float* dist, const float* pos, int n_windows,

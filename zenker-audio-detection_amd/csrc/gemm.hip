@@ -213,7 +213,11 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
           // the guarded block, where it would run with a partial EXEC mask (wrong A/B rows from the masked lanes)
           asm volatile("" : "+v"(v));
           if (m >= a.M) continue;
-          const int b = m / ZK_NPATCH, p = m - b * ZK_NPATCH;
+          // A row m -> (window b, patch p = f·101 + t); with patch_tr the rows hold the time patches t < patch_tr only
+          const int npr = a.patch_tr ? ZK_FOUT * a.patch_tr : ZK_NPATCH;
+          const int b = m / npr;
+          int p = m - b * npr;
+          if (a.patch_tr) { const int f = p / a.patch_tr; p = f * ZK_TOUT + (p - f * a.patch_tr); }
           const f4_t pe = *(const f4_t*)(a.pos + (size_t)(p + 2) * a.N + n);
           *(f4_t*)(a.resid + ((size_t)b * ZK_SEQ + 2 + p) * a.N + n) = v + pe;
         }

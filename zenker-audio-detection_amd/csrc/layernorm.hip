@@ -18,12 +18,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(64 * ZK_LN_WAVES) void layernorm_kernel(const float* __restrict__ x, int64_t row_stride,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int rows, half_t* o_hi,
-                                                        half_t* o_lo, int lo_fmt, int32_t* rowexp, float eps, int rev, int tiled) {
+                                                        half_t* o_lo, int lo_fmt, int32_t* rowexp, float eps, int rev, int tiled, int gather_tr) {
   const int lane = threadIdx.x & 63;
   int row = blockIdx.x * ZK_LN_WAVES + (threadIdx.x >> 6);
   if (row >= rows) return;
   if (rev) row = rows - 1 - row;
-  const float* xr = x + (size_t)row * row_stride;
+  int src_row = row;
+  if (gather_tr) {      // compact row [b][f][t < gather_tr] <- token row b·1214 + 2 + f·101 + t
+    const int npr = ZK_FOUT * gather_tr;
+    const int b = row / npr, r = row - b * npr, f = r / gather_tr;
+    src_row = b * ZK_SEQ + 2 + f * ZK_TOUT + (r - f * gather_tr);
+  }
+  const float* xr = x + (size_t)src_row * row_stride;
   f4_t v[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) v[i] = *(const f4_t*)(xr + i * 256 + lane * 4);
@@ -83,8 +89,8 @@ __global__ __launch_bounds__(64 * ZK_LN_WAVES) void layernorm_kernel(const float
 }  // namespace
 
 void zk_launch_layernorm(const float* x, int64_t row_stride, const float* gamma, const float* beta, int rows,
-                         zk_planes out, float eps, hipStream_t s, int rev) {
+                         zk_planes out, float eps, hipStream_t s, int rev, int gather_tr) {
   if (rows <= 0) return;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + ZK_LN_WAVES - 1) / ZK_LN_WAVES), dim3(64 * ZK_LN_WAVES), 0, s, x, row_stride, gamma, beta, rows,
-                     out.hi, out.lo, out.lo_fmt, (out.lo && out.lo_fmt == ZK_LO_C8) ? out.rowexp : nullptr, eps, rev, out.tiled);
+                     out.hi, out.lo, out.lo_fmt, (out.lo && out.lo_fmt == ZK_LO_C8) ? out.rowexp : nullptr, eps, rev, out.tiled, gather_tr);
 }

@@ -142,19 +142,31 @@ struct zk_gemm_args {
   int64_t x_rows = 0;  // ZK_F16C8: rows the x planes are ALLOCATED for; must cover ceil(M/256)*256 (checked by the launcher)
   int x_tiled = 0;     // ZK_F16C8: the x planes are k-slice-major tiles (zk_planes::tiled)
   int o_tiled = 0;     // ZK_F16C8, GELU epilogue: write the output planes that way (the operand of the next GEMM)
+  // PATCH epilogue: 0 = the A rows are every patch of every window ([b][f][t], 1212 per window); tr > 0: only the time
+  // patches t < tr ([b][f][t < tr], 12·tr per window) — the layer-0 constant-row reuse (zkast.hip) computes the others once
+  int patch_tr = 0;
 };
 
 // launchers (each file owns its kernels)
 void zk_launch_gemm(const zk_gemm_args& a, int epi, int nsplit, hipStream_t s);
 // rev (LayerNorm, attention, zk_gemm_args::rev): process the rows from the last to the first — same results; lets a
 // kernel start on what its producer wrote last (zkast.hip: walk alternation)
+// gather_tr > 0 (layer-0 constant-row reuse): `rows` counts COMPACT rows [b][f][t < gather_tr]; compact row j is read from
+// row b·1214 + 2 + f·101 + t of x and written to row j of the planes
 void zk_launch_layernorm(const float* x, int64_t row_stride, const float* gamma, const float* beta, int rows,
-                         zk_planes out, float eps, hipStream_t s, int rev = 0);
+                         zk_planes out, float eps, hipStream_t s, int rev = 0, int gather_tr = 0);
 void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit, int q_tiles, hipStream_t s, int rev = 0);
 void zk_launch_gather_tok01(zk_planes att, const float* hidden, int n_windows, zk_planes att_out, float* hidden_out,
                             hipStream_t s);
+// t_real > 0: only the time patches t < t_real ([b][f][t < t_real] rows, 12·t_real per window)
 void zk_launch_im2col_compact(const float* feats, int n_frames, const int32_t* win_idx, int n_windows, float mean,
-                              float std2, zk_planes out, hipStream_t s);
+                              float std2, zk_planes out, hipStream_t s, int t_real = 0);
+// layer-0 constant-row reuse (zkast.hip): the rows of a window whose layer-0 input does not depend on the window — cls,
+// distillation and every patch token with t >= t_real (it sees only the extractor's padding) — are copied from a table
+// computed once per model: the fp32 residual rows, and the layer-0 q|k|v planes together with the freshly computed rows
+// of the real tokens (compact [b][f][t < t_real] planes)
+void zk_launch_l0_fill_hidden(float* hidden, const float* table, int n_windows, int t_real, hipStream_t s);
+void zk_launch_l0_assemble_qkv(zk_planes real_rows, zk_planes table, zk_planes out, int n_windows, int t_real, hipStream_t s);
 void zk_launch_im2col_full(const float* input_values, int n_windows, zk_planes out, hipStream_t s);
 void zk_launch_cls_rows(float* hidden, const float* cls, const float* dist, const float* pos, int n_windows,
                         hipStream_t s);

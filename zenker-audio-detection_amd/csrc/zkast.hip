@@ -91,10 +91,17 @@ struct StageModel {
   WMat patch_w;
   LayerW L[ZK_LAYERS];
   float *lnf_g = nullptr, *lnf_b = nullptr, *lnh_g = nullptr, *lnh_b = nullptr, *head_w = nullptr, *head_b = nullptr;
+  // layer-0 constant-row table (build_l0_table): the fp32 residual rows and the layer-0 q|k|v planes of ONE window; valid
+  // for the rows that do not depend on the window, given (n_frames, compute mode, fx mean / std) — l0_frames < 0: not built
+  float* l0_hidden = nullptr;
+  half_t *l0_qkv_hi = nullptr, *l0_qkv_lo = nullptr;
+  int l0_frames = -1, l0_mode = 0;
+  float l0_mean = 0.f, l0_std = 0.f;
   void release() {
     for (void* p : allocs) (void)hipFree(p);
     allocs.clear();
     loaded = false;
+    l0_hidden = nullptr; l0_qkv_hi = l0_qkv_lo = nullptr; l0_frames = -1;
   }
 };
 
@@ -135,6 +142,7 @@ struct zk_ctx {
   PlaneBuf patchA, xn, qkv, att, mid, att_s, xn_s, mid_s;   // *_s: tokens 0/1 only (last-layer pruning)
   DevBuf hidden_s;
   bool prune_last = true;
+  bool l0_reuse = true;      // layer-0 constant-row reuse (zk_set_layer0_reuse)
   int ws_windows = 0;
   bool ws_split = false;
 
@@ -390,7 +398,7 @@ int next_dir(zk_ctx* c) {
 
 int run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, int M, int N, int K, int epi, int nsplit,
               zk_planes out, float* resid, const float* pos, int lo_n_limit, int lo_c8_from = 1 << 30, int rev = 0,
-              int lo_c8_to = 1 << 30) {
+              int lo_c8_to = 1 << 30, int patch_tr = 0) {
   ProfScope ps(c, cls);
   if (c->prof) c->prof_flops[cls] += 2.0 * M * (double)N * K;
   zk_gemm_args a;
@@ -400,6 +408,7 @@ int run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, 
   a.o_hi = out.hi; a.o_lo = (nsplit != ZK_F16) ? out.lo : nullptr;
   a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.lo_c8_from = lo_c8_from; a.lo_c8_to = lo_c8_to; a.w_exp = w.exp;
   a.rev = rev;
+  a.patch_tr = patch_tr;
   a.x_tiled = (nsplit == ZK_F16C8) ? x.tiled : 0;
   a.o_tiled = (nsplit == ZK_F16C8 && epi == ZK_EPI_GELU) ? out.tiled : 0;
   a.x_rows = x.rows_cap / K;      // (PlaneBuf::get states the allocation in elements)
@@ -429,8 +438,11 @@ inline int patch_lo_fmt(int ns) { return patch_mode(ns) == ZK_F16C8 ? ZK_LO_C8 :
 #ifndef ZK_XN_TILED
 #define ZK_XN_TILED 1       // 0: row-major LayerNorm planes in front of QKV / FC1 (A/B switch)
 #endif
-// forward of nb windows (one micro-batch) whose patch matrix is already in c->patchA
-int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
+// forward of nb windows (one micro-batch) whose patch matrix is already in c->patchA.
+// tr > 0: layer-0 constant-row reuse — patchA holds the real time patches only ([b][f][t < tr]); the constant rows of the
+// residual stream and of the layer-0 q|k|v planes come from the model's table (build_l0_table), LayerNorm 1 and the QKV GEMM
+// of layer 0 run on the 12·tr real rows of every window (1.5 % of a forward's FLOPs less; results bit-identical)
+int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0) {
   const int ns = sm.mode;
   const bool sp = ns != ZK_F16;
   // lo-plane format of every GEMM operand: c8 byte pairs in ZK_F16C8 (of the QKV planes only k's columns: attention.hip)
@@ -444,10 +456,11 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
   if (ns == ZK_F16C8) { xn.tiled = ZK_XN_TILED; mid.tiled = ZK_MID_TILED; att.tiled = ZK_ATT_TILED; }
   {
     ProfScope ps(c, P_EMBED);
-    zk_launch_cls_rows(hidden, sm.cls, sm.dist, sm.pos, nb, c->stream);
+    if (tr) zk_launch_l0_fill_hidden(hidden, sm.l0_hidden, nb, tr, c->stream);
+    else zk_launch_cls_rows(hidden, sm.cls, sm.dist, sm.pos, nb, c->stream);
   }
-  if (int grc = run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w, sm.patch_b, nb * ZK_NPATCH, ZK_HIDDEN, ZK_PATCH_K,
-           ZK_EPI_PATCH, patch_mode(ns), zk_planes{nullptr, nullptr, 0}, hidden, sm.pos, 0)) return grc;
+  if (int grc = run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w, sm.patch_b, nb * (tr ? ZK_FOUT * tr : ZK_NPATCH), ZK_HIDDEN, ZK_PATCH_K,
+           ZK_EPI_PATCH, patch_mode(ns), zk_planes{nullptr, nullptr, 0}, hidden, sm.pos, 0, 1 << 30, 0, 1 << 30, tr)) return grc;
   if (c->tap_layer == -1) {
     HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
     HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -461,11 +474,23 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
     // projection and the MLP are needed for those two rows only (exact: same arithmetic per row).  K/V still need every
     // token.  Disabled while a debug tap wants the full residual stream of that layer.
     const bool last = (l == sm.n_layers - 1) && c->prune_last && c->tap_layer != l;
-    { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, M, xn, sm.eps, c->stream, next_dir(c)); }
+    // layer 0 with the constant-row table: LayerNorm 1 and the QKV GEMM see the real rows only (gathered into compact
+    // planes), their q|k|v rows land in the MLP intermediate's buffer (idle until FC1) and one copy kernel assembles the
+    // full planes from them and the table
+    const bool l0 = tr > 0 && l == 0;
+    const int Mq = l0 ? nb * ZK_FOUT * tr : M;
+    zk_planes qkv_dst = qkv;
+    if (l0) { qkv_dst = c->mid.get(sp); qkv_dst.lo_fmt = qkv.lo_fmt; }
+    { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, Mq, xn, sm.eps, c->stream, next_dir(c), l0 ? tr : 0); }
     // lo planes of the fused QKV: q fp16 (re-split by attention), k c8 byte pairs in ZK_F16C8 (fp8-corrected QK^T) else
     // fp16, v fp16 (attention's Vl·P pass)
-    if (int grc = run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, M, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv,
+    if (int grc = run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, Mq, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv_dst,
              nullptr, nullptr, 3 * ZK_HIDDEN, ns == ZK_F16C8 ? ZK_HIDDEN : 1 << 30, next_dir(c), 2 * ZK_HIDDEN)) return grc;
+    if (l0) {
+      ProfScope ps(c, P_EMBED);
+      zk_planes tab{sm.l0_qkv_hi, sp ? sm.l0_qkv_lo : nullptr, qkv.lo_fmt};
+      zk_launch_l0_assemble_qkv(qkv_dst, tab, qkv, nb, tr, c->stream);
+    }
     {
       ProfScope ps(c, P_ATTN);
       const int qt = last ? 1 : 10;
@@ -508,6 +533,50 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits) {
   return ZK_OK;
 }
 
+// Layer-0 constant-row table of a stage model.  A 1 s window fills 98 of the extractor's 1024 frames, so of its 1212 patch
+// tokens only those with t < t_real = ceil(n_frames / 10) (120 of them) see real frames; the input of layer 0 for every
+// other row — cls, distillation, the 1092 padding-only patches — is the same for every window: pad value · patch filters +
+// bias + position.  Their residual rows and their layer-0 LayerNorm + q|k|v rows are therefore computed ONCE, by the
+// ordinary kernels on one window (every kernel involved is row-wise, so a row's bits do not depend on what else is in the
+// launch: the micro-batch invariance tests pin that), and copied from then on.  Depends on the weights, the compute
+// mode, the extractor's mean / std (the pad value) and n_frames.
+int build_l0_table(zk_ctx* c, StageModel& sm, int n_frames) {
+  const int ns = sm.mode;
+  const bool sp = ns != ZK_F16;
+  const int lf = (ns == ZK_F16C8) ? ZK_LO_C8 : ZK_LO_F16;
+  int rc = ensure_workspace(c, 1, sp);
+  if (rc) return rc;
+  if (!sm.l0_hidden) {
+    HIPCHK(c, hipMalloc((void**)&sm.l0_hidden, (size_t)ZK_SEQ * ZK_HIDDEN * 4)); sm.allocs.push_back(sm.l0_hidden);
+    HIPCHK(c, hipMalloc((void**)&sm.l0_qkv_hi, (size_t)ZK_SEQ * 3 * ZK_HIDDEN * 2)); sm.allocs.push_back(sm.l0_qkv_hi);
+    HIPCHK(c, hipMalloc((void**)&sm.l0_qkv_lo, (size_t)ZK_SEQ * 3 * ZK_HIDDEN * 2)); sm.allocs.push_back(sm.l0_qkv_lo);
+  }
+  const bool was_prof = c->prof;
+  c->prof = false;      // a one-off: keep it out of the per-class timings of a profiled region
+  float* hidden = c->hidden.as<float>();
+  zk_planes pa = c->patchA.get(sp, patch_lo_fmt(ns)), xn = c->xn.get(sp, lf), qkv = c->qkv.get(sp);
+  if (ns == ZK_F16C8) xn.tiled = ZK_XN_TILED;
+  const LayerW& L = sm.L[0];
+  // window 0 of the feature slot: which window it is does not matter for the rows that are kept
+  zk_launch_im2col_compact(c->feat.as<float>(), n_frames, nullptr, 1, sm.mean, sm.std * 2.0f, pa, c->stream);
+  zk_launch_cls_rows(hidden, sm.cls, sm.dist, sm.pos, 1, c->stream);
+  rc = run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w, sm.patch_b, ZK_NPATCH, ZK_HIDDEN, ZK_PATCH_K, ZK_EPI_PATCH, patch_mode(ns),
+                zk_planes{nullptr, nullptr, 0}, hidden, sm.pos, 0);
+  if (!rc) {
+    zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, ZK_SEQ, xn, sm.eps, c->stream);
+    rc = run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, ZK_SEQ, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv, nullptr, nullptr,
+                  3 * ZK_HIDDEN, ns == ZK_F16C8 ? ZK_HIDDEN : 1 << 30, 0, 2 * ZK_HIDDEN);
+  }
+  c->prof = was_prof;
+  if (rc) return rc;
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(sm.l0_hidden, hidden, (size_t)ZK_SEQ * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sm.l0_qkv_hi, qkv.hi, (size_t)ZK_SEQ * 3 * ZK_HIDDEN * 2, hipMemcpyDeviceToDevice, c->stream));
+  if (sp) HIPCHK(c, hipMemcpyAsync(sm.l0_qkv_lo, qkv.lo, (size_t)ZK_SEQ * 3 * ZK_HIDDEN * 2, hipMemcpyDeviceToDevice, c->stream));
+  sm.l0_frames = n_frames; sm.l0_mode = ns; sm.l0_mean = sm.mean; sm.l0_std = sm.std;
+  return ZK_OK;
+}
+
 // src_full != nullptr: device (B,1024,128) normalised; else feature slot with optional device index list
 int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d_idx, int B, float* d_logits) {
   StageModel& sm = c->model[stage];
@@ -531,6 +600,15 @@ int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d
   }
   int rc = ensure_workspace(c, B < mbs ? B : mbs, sp);
   if (rc) return rc;
+  // layer-0 constant-row reuse: only for the feature slot (a caller's full (B,1024,128) input may hold anything in its
+  // padding rows) and only when some time patches are padding-only
+  int tr = 0;
+  if (!src_full && c->l0_reuse && c->feat_frames > 0) {
+    tr = (c->feat_frames + ZK_TSTRIDE - 1) / ZK_TSTRIDE;
+    if (tr >= ZK_TOUT) tr = 0;
+  }
+  if (tr && (sm.l0_frames != c->feat_frames || sm.l0_mode != sm.mode || sm.l0_mean != sm.mean || sm.l0_std != sm.std))
+    if ((rc = build_l0_table(c, sm, c->feat_frames))) return rc;
   bool tapped = false;
   const int saved_tap = c->tap_layer;
   for (int b0 = 0; b0 < B; b0 += mbs) {
@@ -542,10 +620,10 @@ int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d
       else
         zk_launch_im2col_compact(c->feat.as<float>() + (d_idx ? 0 : (size_t)b0 * c->feat_frames * ZK_NMEL),
                                  c->feat_frames, d_idx ? d_idx + b0 : nullptr, nb, sm.mean, sm.std * 2.0f,
-                                 c->patchA.get(sp, patch_lo_fmt(sm.mode)), c->stream);
+                                 c->patchA.get(sp, patch_lo_fmt(sm.mode)), c->stream, tr);
     }
     if (tapped) c->tap_layer = -2;  // tap only the first micro-batch
-    rc = forward_micro(c, sm, nb, d_logits + (size_t)b0 * sm.num_labels);
+    rc = forward_micro(c, sm, nb, d_logits + (size_t)b0 * sm.num_labels, tr);
     tapped = true;
     if (rc) { c->tap_layer = saved_tap; return rc; }
   }
@@ -610,6 +688,7 @@ int zk_create(int device_id, zk_ctx** out) {
   if (device_id < 0 || device_id >= n) return fail(nullptr, ZK_E_ARG, "device_id %d out of range [0,%d)", device_id, n);
   zk_ctx* c = new zk_ctx();
   if (const char* wa = getenv("ZK_WALK_ALT")) c->walk_alt = wa[0] == '1';
+  if (const char* lr = getenv("ZK_L0_REUSE")) c->l0_reuse = lr[0] != '0';      // A/B switch; zk_set_layer0_reuse is the API
   c->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess) { delete c; return fail(nullptr, ZK_E_HIP, "hipSetDevice(%d) failed", device_id); }
   hipDeviceProp_t prop;
@@ -1089,6 +1168,7 @@ int zk_prof_get_flops(zk_ctx* c, const char* name, double* flops) {
   return fail(c, ZK_E_ARG, "unknown profile class '%s'", name);
 }
 int zk_set_prune_last_layer(zk_ctx* c, int enable) { if (!c) return ZK_E_ARG; c->prune_last = enable != 0; return ZK_OK; }
+int zk_set_layer0_reuse(zk_ctx* c, int enable) { if (!c) return ZK_E_ARG; c->l0_reuse = enable != 0; return ZK_OK; }
 
 int zk_debug_set_tap(zk_ctx* c, int32_t layer) { if (!c) return ZK_E_ARG; c->tap_layer = layer; c->tap_windows = 0; return ZK_OK; }
 int zk_debug_get_tap(zk_ctx* c, float* out, int32_t n_windows) {

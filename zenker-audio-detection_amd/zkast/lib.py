@@ -27,7 +27,7 @@ COMPUTE_MODES = {"f16": ZK_F16, "f16c8": ZK_F16C8, "f16x3": ZK_F16X3, 1: ZK_F16,
 # every symbol include/zkast.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
     "zk_create", "zk_destroy", "zk_last_error", "zk_set_stream", "zk_set_async", "zk_synchronize",
-    "zk_set_micro_batch", "zk_set_prune_last_layer", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_fx",
+    "zk_set_micro_batch", "zk_set_prune_last_layer", "zk_set_layer0_reuse", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_fx",
     "zk_logmel", "zk_features_expand", "zk_features_get", "zk_features_set", "zk_ast_forward", "zk_softmax", "zk_two_stage", "zk_gate",
     "zk_comm_unique_id", "zk_comm_init", "zk_comm_destroy", "zk_comm_info", "zk_allgather_logits", "zk_comm_allgather_bytes",
     "zk_resample", "zk_wav_decode", "zk_audio_load", "zk_audio_get", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_prof_get_flops", "zk_debug_set_tap", "zk_debug_get_tap",
@@ -138,6 +138,7 @@ def load_library() -> C.CDLL:
             "zk_synchronize": (C.c_int, [vp]),
             "zk_set_micro_batch": (C.c_int, [vp, i32]),
             "zk_set_prune_last_layer": (C.c_int, [vp, C.c_int]),
+            "zk_set_layer0_reuse": (C.c_int, [vp, C.c_int]),
             "zk_version": (C.c_char_p, []),
             "zk_model_load": (C.c_int, [vp, C.c_int, C.POINTER(TensorDesc), i32, C.POINTER(ASTConfigC), f32, f32, i32]),
             "zk_model_set_compute_mode": (C.c_int, [vp, C.c_int, i32]),
@@ -242,6 +243,9 @@ class Context:
 
     def set_prune_last_layer(self, enable: bool):
         self._chk(self.lib.zk_set_prune_last_layer(self.h, int(bool(enable))), "zk_set_prune_last_layer")
+
+    def set_layer0_reuse(self, enable: bool):
+        self._chk(self.lib.zk_set_layer0_reuse(self.h, int(bool(enable))), "zk_set_layer0_reuse")
 
     def set_stream(self, hip_stream: int | None):
         self._chk(self.lib.zk_set_stream(self.h, C.c_void_p(hip_stream or 0)), "zk_set_stream")
