@@ -85,6 +85,40 @@ __global__ __launch_bounds__(256) void gather_tok01_kernel(const half_t* __restr
   *(f4_t*)(h_out + dst) = *(const f4_t*)(hidden + src);
 }
 
+// ---- last-layer pruning, query side (zkast.hip: forward_micro) --------------------------------------------------------------
+// The pruned last layer needs q for tokens 0/1 only.  It is computed for the first ZK_QROWS = 32 tokens of every window — the
+// rows ONE attention wave owns: a wave's deferred-rescale decision is wave-uniform, so tokens 0/1 keep their exact bits only
+// if their 30 wave-mates carry the same q as in the unpruned forward.  Their LayerNorm rows are gathered into compact planes
+// (with their row exponents), a 32-rows-per-window GEMM computes q, and the rows go back to columns 0..767 of the window's
+// q|k|v planes.  one thread = 8 channels of one row
+__global__ __launch_bounds__(256) void gather_xq_kernel(const half_t* __restrict__ x_hi, const half_t* __restrict__ x_lo,
+                                                        const int32_t* __restrict__ x_exp, int x_tiled, int n_windows,
+                                                        half_t* __restrict__ o_hi, half_t* __restrict__ o_lo,
+                                                        int32_t* __restrict__ o_exp) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n_windows * ZK_QROWS * (ZK_HIDDEN / 8)) return;
+  const int c8 = gid % (ZK_HIDDEN / 8);
+  const int r = gid / (ZK_HIDDEN / 8);                   // b*ZK_QROWS + tok
+  const int srow = (r / ZK_QROWS) * ZK_SEQ + (r % ZK_QROWS);
+  const size_t src = x_tiled ? zk_tiled_off(srow, c8 * 8, ZK_HIDDEN) : (size_t)srow * ZK_HIDDEN + c8 * 8;
+  const size_t dst = (size_t)r * ZK_HIDDEN + c8 * 8;
+  *(h8_t*)(o_hi + dst) = *(const h8_t*)(x_hi + src);
+  if (o_lo) *(h8_t*)(o_lo + dst) = *(const h8_t*)(x_lo + src);
+  if (o_exp && c8 == 0) o_exp[r] = x_exp ? x_exp[srow] : 0;
+}
+
+__global__ __launch_bounds__(256) void scatter_q_kernel(const half_t* __restrict__ q_hi, const half_t* __restrict__ q_lo,
+                                                        int n_windows, half_t* __restrict__ o_hi, half_t* __restrict__ o_lo) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n_windows * ZK_QROWS * (ZK_HIDDEN / 8)) return;
+  const int c8 = gid % (ZK_HIDDEN / 8);
+  const int r = gid / (ZK_HIDDEN / 8);
+  const size_t src = (size_t)r * ZK_HIDDEN + c8 * 8;
+  const size_t dst = ((size_t)(r / ZK_QROWS) * ZK_SEQ + (r % ZK_QROWS)) * (3 * ZK_HIDDEN) + c8 * 8;
+  *(h8_t*)(o_hi + dst) = *(const h8_t*)(q_hi + src);
+  if (o_lo) *(h8_t*)(o_lo + dst) = *(const h8_t*)(q_lo + src);
+}
+
 // ---- layer-0 constant-row reuse (zkast.hip: build_l0_table) ---------------------------------------------------------------
 // Of a window's 1214 token rows only the 12·t_real patch tokens with t < t_real see real frames (t_real = ceil(n_frames / 10)
 // = 10 for a 1 s window); cls, distillation and the other patch tokens have a layer-0 input that is the same for every
@@ -124,8 +158,10 @@ __global__ __launch_bounds__(256) void l0_assemble_qkv_kernel(const half_t* __re
     }
   }
   const size_t oo = (size_t)rr * (3 * ZK_HIDDEN) + ch * 8;
-  *(h8_t*)(o_hi + oo) = *(const h8_t*)(sh + ch * 8);
-  if (o_lo) *(h8_t*)(o_lo + oo) = *(const h8_t*)(sl + ch * 8);
+  // (non-temporal: 11 MB per window that the attention kernel reads back from HBM much later; the table and the real rows
+  // stay in the caches instead)
+  __builtin_nontemporal_store(*(const h8_t*)(sh + ch * 8), (h8_t*)(o_hi + oo));
+  if (o_lo) __builtin_nontemporal_store(*(const h8_t*)(sl + ch * 8), (h8_t*)(o_lo + oo));
 }
 
 }  // namespace
@@ -144,6 +180,19 @@ void zk_launch_im2col_compact(const float* feats, int n_frames, const int32_t* w
   const int64_t total = (int64_t)n_windows * (t_real ? ZK_FOUT * t_real : ZK_NPATCH) * 32;
   hipLaunchKernelGGL(im2col_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feats, n_frames,
                      win_idx, n_windows, mean, std2, out.hi, out.lo, out.lo_fmt, t_real);
+}
+
+void zk_launch_gather_xq(zk_planes x, int n_windows, zk_planes out, hipStream_t s) {
+  if (n_windows <= 0) return;
+  const int total = n_windows * ZK_QROWS * (ZK_HIDDEN / 8);
+  hipLaunchKernelGGL(gather_xq_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x.hi, x.lo, x.rowexp, x.tiled, n_windows, out.hi,
+                     out.lo, out.rowexp);
+}
+
+void zk_launch_scatter_q(zk_planes q, int n_windows, zk_planes qkv, hipStream_t s) {
+  if (n_windows <= 0) return;
+  const int total = n_windows * ZK_QROWS * (ZK_HIDDEN / 8);
+  hipLaunchKernelGGL(scatter_q_kernel, dim3((total + 255) / 256), dim3(256), 0, s, q.hi, q.lo, n_windows, qkv.hi, qkv.lo);
 }
 
 void zk_launch_l0_fill_hidden(float* hidden, const float* table, int n_windows, int t_real, hipStream_t s) {

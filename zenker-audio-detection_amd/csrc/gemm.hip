@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
         for (int t = 0; t < 2; ++t) {
           const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
           const int m = m0 + j * 16 + rd_row + 8 * t;
-          if (m < a.M) *(h8_t*)(a.o_hi + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+          if (m < a.M) *(h8_t*)(a.o_hi + (size_t)m * a.ldo + n0 + rd_ch * 8) = v;
         }
         if (want_lo) {
 #pragma unroll
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const zk_gemm_args a) {
           for (int t = 0; t < 2; ++t) {
             const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
             const int m = m0 + j * 16 + rd_row + 8 * t;
-            if (m < a.M) *(h8_t*)(a.o_lo + (size_t)m * a.N + n0 + rd_ch * 8) = v;
+            if (m < a.M) *(h8_t*)(a.o_lo + (size_t)m * a.ldo + n0 + rd_ch * 8) = v;
           }
         }
       }
@@ -372,7 +372,9 @@ void launch_epi(const zk_gemm_args& a, int epi, hipStream_t s) {
 
 // Host-side shape contract (checked by the caller, zkast.hip): N % 256 == 0, K % 64 == 0, M >= 1, all planes
 // 16-byte aligned, x planes hold at least M rows.
-void zk_launch_gemm(const zk_gemm_args& a, int epi, int nsplit, hipStream_t s) {
+void zk_launch_gemm(const zk_gemm_args& a_in, int epi, int nsplit, hipStream_t s) {
+  zk_gemm_args a = a_in;
+  if (a.ldo == 0) a.ldo = a.N;
   if (nsplit == 3) launch_epi<3>(a, epi, s);
   else launch_epi<1>(a, epi, s);
 }

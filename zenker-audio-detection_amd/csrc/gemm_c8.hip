@@ -498,7 +498,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
             const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
             const int m = m0 + j * 16 + rd_row + 8 * t;
             // this lane's 8 halves in a plane: row-major, or the tile form (uniform tile base + 32-bit lane offset: see tl_off)
-            const size_t oo = TILED_OUT ? tl_base + (size_t)(tl_off[t] + j * 1024) : (size_t)m * a.N + n0 + rd_ch * 8;
+            const size_t oo = TILED_OUT ? tl_base + (size_t)(tl_off[t] + j * 1024) : (size_t)m * a.ldo + n0 + rd_ch * 8;
             // (non-temporal: the planes are read by the NEXT kernel from their first row on, long after these lines would have
             // left the caches; kept out of L2 they stop evicting the W / X lines of the k-loops: FC1 +2 %, QKV +0.7 %)
 #ifdef ZK_C8_NO_NT      // probe builds: plain stores
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
             for (int t = 0; t < 2; ++t) {
               const h8_t v = *(const h8_t*)(scr + (rd_row + 8 * t) * SCR_STR + rd_ch * 16);
               const int m = m0 + j * 16 + rd_row + 8 * t;
-              const size_t oo = TILED_OUT ? tl_base + (size_t)(tl_off[t] + j * 1024) : (size_t)m * a.N + n0 + rd_ch * 8;
+              const size_t oo = TILED_OUT ? tl_base + (size_t)(tl_off[t] + j * 1024) : (size_t)m * a.ldo + n0 + rd_ch * 8;
 #ifdef ZK_C8_NO_NT
               if (m < a.M) *(h8_t*)(a.o_lo + oo) = v;
 #else
@@ -705,8 +705,10 @@ void launch_cfg(const zk_gemm_args& a, hipStream_t s) {
 // Host-side shape contract as zk_launch_gemm: N % 256 == 0, K % 64 == 0, M >= 1; x_lo / w_lo are c8 planes.  The kernel
 // stages the last 256-row block of x WHOLE (no M-tail clamp in the loader), so the planes must be allocated for
 // ceil(M/256)*256 rows: the caller states the allocation in x_rows and the launch is refused if it falls short.
-int zk_launch_gemm_c8(const zk_gemm_args& a, int epi, hipStream_t s) {
-  if (a.M < 1 || a.N % 256 || a.K % 64) return -1;
+int zk_launch_gemm_c8(const zk_gemm_args& a_in, int epi, hipStream_t s) {
+  zk_gemm_args a = a_in;
+  if (a.ldo == 0) a.ldo = a.N;
+  if (a.M < 1 || a.N % 256 || a.K % 64 || a.ldo < a.N || a.ldo % 8) return -1;
   if (a.x_rows < (int64_t)((a.M + 255) / 256) * 256) return -1;
   switch (epi) {
     case ZK_EPI_STORE: if (a.x_tiled) launch_cfg<ZK_EPI_STORE, true>(a, s); else launch_cfg<ZK_EPI_STORE>(a, s); break;

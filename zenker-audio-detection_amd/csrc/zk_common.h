@@ -129,6 +129,8 @@ struct zk_gemm_args {
   const float* bias;   // [N]
   const int32_t* x_rowexp;  // [M] or nullptr: row m of the x planes holds x·2^-x_rowexp[m] (zk_planes::rowexp)
   int M, N, K;
+  int ldo = 0;         // STORE / GELU, row-major output planes: elements between two output rows (the launchers set N when 0);
+                       // > N writes an N-column band of wider planes (the last layer's k|v-only QKV launch)
   // outputs
   half_t* o_hi;        // [M, N] (STORE / GELU)
   half_t* o_lo;
@@ -165,6 +167,11 @@ void zk_launch_im2col_compact(const float* feats, int n_frames, const int32_t* w
 // distillation and every patch token with t >= t_real (it sees only the extractor's padding) — are copied from a table
 // computed once per model: the fp32 residual rows, and the layer-0 q|k|v planes together with the freshly computed rows
 // of the real tokens (compact [b][f][t < t_real] planes)
+// last-layer pruning, query side: LayerNorm rows 0 .. ZK_QROWS-1 of every window -> compact planes [ZK_QROWS·n_windows, 768]
+// (row exponents included), and the compact q rows back into columns 0..767 of those rows of the windows' q|k|v planes
+#define ZK_QROWS 32      // = the query rows of one attention wave (attention.hip: q_row = tile·256 + wave·32 + lane % 32)
+void zk_launch_gather_xq(zk_planes x, int n_windows, zk_planes out, hipStream_t s);
+void zk_launch_scatter_q(zk_planes q, int n_windows, zk_planes qkv, hipStream_t s);
 void zk_launch_l0_fill_hidden(float* hidden, const float* table, int n_windows, int t_real, hipStream_t s);
 void zk_launch_l0_assemble_qkv(zk_planes real_rows, zk_planes table, zk_planes out, int n_windows, int t_real, hipStream_t s);
 void zk_launch_im2col_full(const float* input_values, int n_windows, zk_planes out, hipStream_t s);

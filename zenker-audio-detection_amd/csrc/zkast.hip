@@ -141,6 +141,7 @@ struct zk_ctx {
   DevBuf hidden;
   PlaneBuf patchA, xn, qkv, att, mid, att_s, xn_s, mid_s;   // *_s: tokens 0/1 only (last-layer pruning)
   DevBuf hidden_s;
+  DevBuf xq_rowexp;      // row exponents of the gathered LayerNorm rows of the pruned last layer's q GEMM (ZK_QROWS per window)
   bool prune_last = true;
   bool l0_reuse = true;      // layer-0 constant-row reuse (zk_set_layer0_reuse)
   int ws_windows = 0;
@@ -382,6 +383,7 @@ int ensure_workspace(zk_ctx* c, int windows, bool split) {
   HIPCHK(c, pl(c->att_s, Ms * ZK_HIDDEN));
   HIPCHK(c, pl(c->xn_s, Ms * ZK_HIDDEN));
   if (sp) HIPCHK(c, c->xn_s.rowexp.ensure(Ms * 4));
+  if (sp) HIPCHK(c, c->xq_rowexp.ensure(((size_t)w * ZK_QROWS + 256) * 4));
   HIPCHK(c, pl(c->mid_s, Ms * ZK_INTER));
   c->ws_windows = w;
   c->ws_split = sp;
@@ -398,7 +400,7 @@ int next_dir(zk_ctx* c) {
 
 int run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, int M, int N, int K, int epi, int nsplit,
               zk_planes out, float* resid, const float* pos, int lo_n_limit, int lo_c8_from = 1 << 30, int rev = 0,
-              int lo_c8_to = 1 << 30, int patch_tr = 0) {
+              int lo_c8_to = 1 << 30, int patch_tr = 0, int ldo = 0) {
   ProfScope ps(c, cls);
   if (c->prof) c->prof_flops[cls] += 2.0 * M * (double)N * K;
   zk_gemm_args a;
@@ -409,6 +411,7 @@ int run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, 
   a.resid = resid; a.pos = pos; a.lo_n_limit = lo_n_limit; a.lo_c8_from = lo_c8_from; a.lo_c8_to = lo_c8_to; a.w_exp = w.exp;
   a.rev = rev;
   a.patch_tr = patch_tr;
+  a.ldo = ldo;
   a.x_tiled = (nsplit == ZK_F16C8) ? x.tiled : 0;
   a.o_tiled = (nsplit == ZK_F16C8 && epi == ZK_EPI_GELU) ? out.tiled : 0;
   a.x_rows = x.rows_cap / K;      // (PlaneBuf::get states the allocation in elements)
@@ -429,6 +432,9 @@ int run_gemm(zk_ctx* c, int cls, zk_planes x, const WMat& w, const float* bias, 
 inline int patch_mode(int ns) { return (ZK_PATCH_X3 && ns == ZK_F16C8) ? ZK_F16X3 : ns; }
 inline int patch_lo_fmt(int ns) { return patch_mode(ns) == ZK_F16C8 ? ZK_LO_C8 : ZK_LO_F16; }
 
+#ifndef ZK_PRUNE_Q
+#define ZK_PRUNE_Q 1        // 0: the pruned last layer still computes q for every token (A/B switch)
+#endif
 #ifndef ZK_MID_TILED
 #define ZK_MID_TILED 1      // 0: row-major GELU planes between FC1 and FC2 (A/B switch)
 #endif
@@ -484,6 +490,27 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0
     { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, Mq, xn, sm.eps, c->stream, next_dir(c), l0 ? tr : 0); }
     // lo planes of the fused QKV: q fp16 (re-split by attention), k c8 byte pairs in ZK_F16C8 (fp8-corrected QK^T) else
     // fp16, v fp16 (attention's Vl·P pass)
+    if (last && !l0 && ZK_PRUNE_Q) {
+      // pruned last layer: k and v are needed for every token, q only for the tokens whose attention output is read —
+      // tokens 0/1, computed together with the other 30 rows of their attention wave (ZK_QROWS: the wave's rescale decision
+      // is wave-uniform, so the bits of rows 0/1 depend on what their wave-mates hold; with the whole wave's q exact the
+      // logits equal the unpruned forward's bit for bit).  What the remaining rows of the query tile hold as "q" — the
+      // previous layer's — only reaches output rows nobody reads.  The fused launch is cut to the k|v columns (a band of
+      // the same planes: ldo = 2304); q comes from a 32-rows-per-window GEMM on gathered LayerNorm rows, staged in the MLP
+      // intermediate's and the attention output's buffers (both idle at this point).
+      WMat wkv = L.wqkv;
+      wkv.hi += (size_t)ZK_HIDDEN * ZK_HIDDEN; wkv.lo += (size_t)ZK_HIDDEN * ZK_HIDDEN; wkv.c8 += (size_t)ZK_HIDDEN * ZK_HIDDEN;
+      zk_planes kv = qkv;
+      kv.hi += ZK_HIDDEN; if (kv.lo) kv.lo += ZK_HIDDEN;
+      if (int grc = run_gemm(c, P_GEMM_QKV, xn, wkv, L.bqkv + ZK_HIDDEN, M, 2 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, kv,
+               nullptr, nullptr, 2 * ZK_HIDDEN, ns == ZK_F16C8 ? 0 : 1 << 30, next_dir(c), ZK_HIDDEN, 0, 3 * ZK_HIDDEN)) return grc;
+      zk_planes xq = c->mid.get(sp, lf), q32 = c->att.get(sp);
+      xq.rowexp = (sp && lf == ZK_LO_C8) ? c->xq_rowexp.as<int32_t>() : nullptr;
+      { ProfScope ps(c, P_EMBED); zk_launch_gather_xq(xn, nb, xq, c->stream); }
+      if (int grc = run_gemm(c, P_GEMM_QKV, xq, L.wqkv, L.bqkv, ZK_QROWS * nb, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, q32,
+               nullptr, nullptr, ZK_HIDDEN)) return grc;
+      { ProfScope ps(c, P_EMBED); zk_launch_scatter_q(q32, nb, qkv, c->stream); }
+    } else
     if (int grc = run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, Mq, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv_dst,
              nullptr, nullptr, 3 * ZK_HIDDEN, ns == ZK_F16C8 ? ZK_HIDDEN : 1 << 30, next_dir(c), 2 * ZK_HIDDEN)) return grc;
     if (l0) {
@@ -728,6 +755,7 @@ void zk_destroy(zk_ctx* c) {
                     &c->gate_cnt, &c->tmp_f32, &c->hidden, &c->rs_kern, &c->tap})
     b->release();
   c->hidden_s.release();
+  c->xq_rowexp.release();
   for (PlaneBuf* b : {&c->patchA, &c->xn, &c->qkv, &c->att, &c->mid, &c->att_s, &c->xn_s, &c->mid_s}) { b->hi.release(); b->lo.release(); b->rowexp.release(); }
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
