@@ -504,7 +504,7 @@ def main():
             return
         t0 = time.perf_counter()
         left = args.time_budget_s - (t0 - t_bench0)
-        if left < need_s:
+        if world == 1 and left < need_s:      # (N > 1: the legs contain collectives — every rank must take the same decision)
             out["legs"][name] = f"skipped: {left:.0f} s left of --time-budget-s {args.time_budget_s:.0f}, leg needs ~{need_s:.0f}"
             return
         try:

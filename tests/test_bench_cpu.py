@@ -100,7 +100,7 @@ def test_bench_leg_guard_records_errors_and_still_prints(tmp_path):
     code = (
         "import json, os, signal, sys, time, traceback\n"
         "class A: time_budget_s = 1000.0\n"
-        "args, rank, out, t_bench0 = A(), 0, {'value': 1.0}, time.perf_counter()\n"
+        "args, rank, world, out, t_bench0 = A(), 0, 1, {'value': 1.0}, time.perf_counter()\n"
         "real_stdout = os.dup(1)\n" + body +
         "def boom(): raise TypeError(\"'NoneType' object is not subscriptable\")\n"
         "leg('cpu_baseline', boom)\n"

@@ -123,31 +123,26 @@ __global__ __launch_bounds__(256) void scatter_q_kernel(const half_t* __restrict
 // Of a window's 1214 token rows only the 12·t_real patch tokens with t < t_real see real frames (t_real = ceil(n_frames / 10)
 // = 10 for a 1 s window); cls, distillation and the other patch tokens have a layer-0 input that is the same for every
 // window.  Their residual rows and their layer-0 q|k|v rows come from a table, bit-identical to computing them.
-// one thread = 4 channels of one constant row
-__global__ __launch_bounds__(256) void l0_fill_hidden_kernel(float* __restrict__ hidden, const float* __restrict__ table,
+// one workgroup = one constant row of one window (192 threads x 4 channels); the row arithmetic is wave-uniform
+__global__ __launch_bounds__(192) void l0_fill_hidden_kernel(float* __restrict__ hidden, const float* __restrict__ table,
                                                              int n_windows, int t_real) {
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int tpad = ZK_TOUT - t_real, nconst = 2 + ZK_FOUT * tpad;
-  if (gid >= (int64_t)n_windows * nconst * (ZK_HIDDEN / 4)) return;
-  const int c4 = (int)(gid % (ZK_HIDDEN / 4));
-  const int64_t rr = gid / (ZK_HIDDEN / 4);
-  const int b = (int)(rr / nconst), i = (int)(rr - (int64_t)b * nconst);
+  const int b = blockIdx.x / nconst, i = blockIdx.x - b * nconst;
   int row = i;
   if (i >= 2) { const int j = i - 2, f = j / tpad; row = 2 + f * ZK_TOUT + t_real + (j - f * tpad); }
-  *(f4_t*)(hidden + ((size_t)b * ZK_SEQ + row) * ZK_HIDDEN + c4 * 4) = *(const f4_t*)(table + (size_t)row * ZK_HIDDEN + c4 * 4);
+  const int c4 = threadIdx.x;
+  __builtin_nontemporal_store(*(const f4_t*)(table + (size_t)row * ZK_HIDDEN + c4 * 4),
+                              (f4_t*)(hidden + ((size_t)b * ZK_SEQ + row) * ZK_HIDDEN + c4 * 4));
 }
 
-// one thread = one 16-byte chunk of one token row, both planes
-__global__ __launch_bounds__(256) void l0_assemble_qkv_kernel(const half_t* __restrict__ r_hi, const half_t* __restrict__ r_lo,
+// one workgroup = one token row of one window: 288 threads x 16 bytes, both planes; which source the row comes from (the
+// table or the freshly computed real rows) is decided once per workgroup
+__global__ __launch_bounds__(320) void l0_assemble_qkv_kernel(const half_t* __restrict__ r_hi, const half_t* __restrict__ r_lo,
                                                               const half_t* __restrict__ t_hi, const half_t* __restrict__ t_lo,
                                                               half_t* __restrict__ o_hi, half_t* __restrict__ o_lo, int n_windows,
                                                               int t_real) {
   constexpr int CH = 3 * ZK_HIDDEN / 8;
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (int64_t)n_windows * ZK_SEQ * CH) return;
-  const int ch = (int)(gid % CH);
-  const int64_t rr = gid / CH;
-  const int b = (int)(rr / ZK_SEQ), row = (int)(rr - (int64_t)b * ZK_SEQ);
+  const int b = blockIdx.x / ZK_SEQ, row = blockIdx.x - b * ZK_SEQ;
   const half_t *sh = t_hi + (size_t)row * (3 * ZK_HIDDEN), *sl = t_lo ? t_lo + (size_t)row * (3 * ZK_HIDDEN) : nullptr;
   if (row >= 2) {
     const int p = row - 2, f = p / ZK_TOUT, t = p - f * ZK_TOUT;
@@ -157,7 +152,9 @@ __global__ __launch_bounds__(256) void l0_assemble_qkv_kernel(const half_t* __re
       sl = r_lo ? r_lo + r * (3 * ZK_HIDDEN) : nullptr;
     }
   }
-  const size_t oo = (size_t)rr * (3 * ZK_HIDDEN) + ch * 8;
+  const int ch = threadIdx.x;
+  if (ch >= CH) return;
+  const size_t oo = (size_t)blockIdx.x * (3 * ZK_HIDDEN) + ch * 8;
   // (non-temporal: 11 MB per window that the attention kernel reads back from HBM much later; the table and the real rows
   // stay in the caches instead)
   __builtin_nontemporal_store(*(const h8_t*)(sh + ch * 8), (h8_t*)(o_hi + oo));
@@ -198,14 +195,12 @@ void zk_launch_scatter_q(zk_planes q, int n_windows, zk_planes qkv, hipStream_t 
 void zk_launch_l0_fill_hidden(float* hidden, const float* table, int n_windows, int t_real, hipStream_t s) {
   if (n_windows <= 0) return;
   const int nconst = 2 + ZK_FOUT * (ZK_TOUT - t_real);
-  const int64_t total = (int64_t)n_windows * nconst * (ZK_HIDDEN / 4);
-  hipLaunchKernelGGL(l0_fill_hidden_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hidden, table, n_windows, t_real);
+  hipLaunchKernelGGL(l0_fill_hidden_kernel, dim3((unsigned)(n_windows * nconst)), dim3(ZK_HIDDEN / 4), 0, s, hidden, table, n_windows, t_real);
 }
 
 void zk_launch_l0_assemble_qkv(zk_planes real_rows, zk_planes table, zk_planes out, int n_windows, int t_real, hipStream_t s) {
   if (n_windows <= 0) return;
-  const int64_t total = (int64_t)n_windows * ZK_SEQ * (3 * ZK_HIDDEN / 8);
-  hipLaunchKernelGGL(l0_assemble_qkv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, real_rows.hi, real_rows.lo,
+  hipLaunchKernelGGL(l0_assemble_qkv_kernel, dim3((unsigned)(n_windows * ZK_SEQ)), dim3(320), 0, s, real_rows.hi, real_rows.lo,
                      table.hi, table.lo, out.hi, out.lo, n_windows, t_real);
 }
 
