@@ -788,8 +788,9 @@ void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit
   if (n_windows <= 0) return;
   // q_tiles counts 128-row query blocks (< 10: only the first q_tiles*128 query rows, the last layer's pruning); the
   // kernel's workgroup covers QT = 32·NW rows, waves beyond the row limit only help staging
-  if (q_tiles <= 0 || q_tiles > 10) q_tiles = 10;
-  const int row_limit = q_tiles * 128;
+  // (q_tiles < 0: a limit in ROWS, -q_tiles of them — the pruned last layer asks for one wave's 32)
+  if (q_tiles == 0 || q_tiles > 10) q_tiles = 10;
+  const int row_limit = q_tiles < 0 ? -q_tiles : q_tiles * 128;
   const int wg_tiles = (row_limit < S_ ? row_limit + QT - 1 : S_ + QT - 1) / QT;
   const int grid = wg_tiles * ZK_HEADS * n_windows;
   auto go = [&](auto kernel, int lds) {

@@ -123,42 +123,54 @@ __global__ __launch_bounds__(256) void scatter_q_kernel(const half_t* __restrict
 // Of a window's 1214 token rows only the 12·t_real patch tokens with t < t_real see real frames (t_real = ceil(n_frames / 10)
 // = 10 for a 1 s window); cls, distillation and the other patch tokens have a layer-0 input that is the same for every
 // window.  Their residual rows and their layer-0 q|k|v rows come from a table, bit-identical to computing them.
-// one workgroup = one constant row of one window (192 threads x 4 channels); the row arithmetic is wave-uniform
+// one workgroup = one constant row of ZK_L0_WPB consecutive windows (192 threads x 4 channels): read once, stored 8 times
 __global__ __launch_bounds__(192) void l0_fill_hidden_kernel(float* __restrict__ hidden, const float* __restrict__ table,
                                                              int n_windows, int t_real) {
   const int tpad = ZK_TOUT - t_real, nconst = 2 + ZK_FOUT * tpad;
-  const int b = blockIdx.x / nconst, i = blockIdx.x - b * nconst;
+  const int i = blockIdx.x % nconst, b0 = (blockIdx.x / nconst) * 8;
   int row = i;
   if (i >= 2) { const int j = i - 2, f = j / tpad; row = 2 + f * ZK_TOUT + t_real + (j - f * tpad); }
   const int c4 = threadIdx.x;
-  __builtin_nontemporal_store(*(const f4_t*)(table + (size_t)row * ZK_HIDDEN + c4 * 4),
-                              (f4_t*)(hidden + ((size_t)b * ZK_SEQ + row) * ZK_HIDDEN + c4 * 4));
+  const f4_t v = *(const f4_t*)(table + (size_t)row * ZK_HIDDEN + c4 * 4);
+#pragma unroll
+  for (int w = 0; w < 8; ++w)
+    if (b0 + w < n_windows)
+      __builtin_nontemporal_store(v, (f4_t*)(hidden + ((size_t)(b0 + w) * ZK_SEQ + row) * ZK_HIDDEN + c4 * 4));
 }
 
-// one workgroup = one token row of one window: 288 threads x 16 bytes, both planes; which source the row comes from (the
-// table or the freshly computed real rows) is decided once per workgroup
+// one workgroup = one token row of ZK_L0_WPB consecutive windows: 288 threads x 16 bytes, both planes.  Which source the row
+// comes from is decided once per workgroup; a constant row is read from the table ONCE and stored ZK_L0_WPB times
+#define ZK_L0_WPB 8
 __global__ __launch_bounds__(320) void l0_assemble_qkv_kernel(const half_t* __restrict__ r_hi, const half_t* __restrict__ r_lo,
                                                               const half_t* __restrict__ t_hi, const half_t* __restrict__ t_lo,
                                                               half_t* __restrict__ o_hi, half_t* __restrict__ o_lo, int n_windows,
                                                               int t_real) {
-  constexpr int CH = 3 * ZK_HIDDEN / 8;
-  const int b = blockIdx.x / ZK_SEQ, row = blockIdx.x - b * ZK_SEQ;
-  const half_t *sh = t_hi + (size_t)row * (3 * ZK_HIDDEN), *sl = t_lo ? t_lo + (size_t)row * (3 * ZK_HIDDEN) : nullptr;
-  if (row >= 2) {
-    const int p = row - 2, f = p / ZK_TOUT, t = p - f * ZK_TOUT;
-    if (t < t_real) {
-      const size_t r = ((size_t)b * ZK_FOUT + f) * t_real + t;
-      sh = r_hi + r * (3 * ZK_HIDDEN);
-      sl = r_lo ? r_lo + r * (3 * ZK_HIDDEN) : nullptr;
-    }
-  }
+  constexpr int CH = 3 * ZK_HIDDEN / 8, LD = 3 * ZK_HIDDEN;
+  const int row = blockIdx.x % ZK_SEQ, b0 = (blockIdx.x / ZK_SEQ) * ZK_L0_WPB;
   const int ch = threadIdx.x;
   if (ch >= CH) return;
-  const size_t oo = (size_t)blockIdx.x * (3 * ZK_HIDDEN) + ch * 8;
-  // (non-temporal: 11 MB per window that the attention kernel reads back from HBM much later; the table and the real rows
-  // stay in the caches instead)
-  __builtin_nontemporal_store(*(const h8_t*)(sh + ch * 8), (h8_t*)(o_hi + oo));
-  if (o_lo) __builtin_nontemporal_store(*(const h8_t*)(sl + ch * 8), (h8_t*)(o_lo + oo));
+  int f = 0, t = ZK_TOUT;
+  if (row >= 2) { const int p = row - 2; f = p / ZK_TOUT; t = p - f * ZK_TOUT; }
+  const bool real = t < t_real;
+  h8_t vh, vl;
+  if (!real) {
+    vh = *(const h8_t*)(t_hi + (size_t)row * LD + ch * 8);
+    if (o_lo) vl = *(const h8_t*)(t_lo + (size_t)row * LD + ch * 8);
+  }
+#pragma unroll 4
+  for (int w = 0; w < ZK_L0_WPB; ++w) {
+    const int b = b0 + w;
+    if (b >= n_windows) break;
+    if (real) {
+      const size_t r = ((size_t)b * ZK_FOUT + f) * t_real + t;
+      vh = *(const h8_t*)(r_hi + r * LD + ch * 8);
+      if (o_lo) vl = *(const h8_t*)(r_lo + r * LD + ch * 8);
+    }
+    const size_t oo = ((size_t)b * ZK_SEQ + row) * LD + ch * 8;
+    // (non-temporal: 11 MB per window that the attention kernel reads back from HBM much later)
+    __builtin_nontemporal_store(vh, (h8_t*)(o_hi + oo));
+    if (o_lo) __builtin_nontemporal_store(vl, (h8_t*)(o_lo + oo));
+  }
 }
 
 }  // namespace
@@ -195,12 +207,12 @@ void zk_launch_scatter_q(zk_planes q, int n_windows, zk_planes qkv, hipStream_t 
 void zk_launch_l0_fill_hidden(float* hidden, const float* table, int n_windows, int t_real, hipStream_t s) {
   if (n_windows <= 0) return;
   const int nconst = 2 + ZK_FOUT * (ZK_TOUT - t_real);
-  hipLaunchKernelGGL(l0_fill_hidden_kernel, dim3((unsigned)(n_windows * nconst)), dim3(ZK_HIDDEN / 4), 0, s, hidden, table, n_windows, t_real);
+  hipLaunchKernelGGL(l0_fill_hidden_kernel, dim3((unsigned)(((n_windows + 7) / 8) * nconst)), dim3(ZK_HIDDEN / 4), 0, s, hidden, table, n_windows, t_real);
 }
 
 void zk_launch_l0_assemble_qkv(zk_planes real_rows, zk_planes table, zk_planes out, int n_windows, int t_real, hipStream_t s) {
   if (n_windows <= 0) return;
-  hipLaunchKernelGGL(l0_assemble_qkv_kernel, dim3((unsigned)(n_windows * ZK_SEQ)), dim3(320), 0, s, real_rows.hi, real_rows.lo,
+  hipLaunchKernelGGL(l0_assemble_qkv_kernel, dim3((unsigned)(((n_windows + ZK_L0_WPB - 1) / ZK_L0_WPB) * ZK_SEQ)), dim3(320), 0, s, real_rows.hi, real_rows.lo,
                      table.hi, table.lo, out.hi, out.lo, n_windows, t_real);
 }
 

@@ -520,8 +520,11 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0
     }
     {
       ProfScope ps(c, P_ATTN);
-      const int qt = last ? 1 : 10;
-      if (c->prof) c->prof_flops[P_ATTN] += (double)nb * ZK_HEADS * 4.0 * (qt == 1 ? 128.0 : (double)ZK_SEQ) * ZK_SEQ * ZK_HEAD_DIM;
+      // pruned last layer: only the query rows whose q exists are worth computing — one wave's 32 with ZK_PRUNE_Q (the
+      // other waves of the workgroup still help staging K / V), else the first 128-row block
+      const bool q32 = last && l > 0 && ZK_PRUNE_Q == 1;
+      const int qt = last ? (q32 ? -ZK_QROWS : 1) : 10;
+      if (c->prof) c->prof_flops[P_ATTN] += (double)nb * ZK_HEADS * 4.0 * (last ? (q32 ? (double)ZK_QROWS : 128.0) : (double)ZK_SEQ) * ZK_SEQ * ZK_HEAD_DIM;
       zk_launch_attention(qkv, att, nb, ns == ZK_F16C8 ? 2 : (sp ? 3 : 1), qt, c->stream, next_dir(c));
     }
     if (last) {
