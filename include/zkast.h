@@ -193,6 +193,9 @@ int zk_debug_get_tap(zk_ctx* ctx, float* out /*host*/, int32_t n_windows);
 /* zk_test_gemm: the rows M .. ceil(M/256)*256 of the hook's x planes hold NaN patterns instead of zeros (the ZK_F16C8
  * kernel reads its last row block whole; what lies behind row M must never reach a result)                           */
 #define ZK_TEST_POISON_PAD 0x400
+/* zk_test_gemm: tell the ZK_F16C8 launcher that the x planes are allocated for exactly M rows; it must refuse the launch
+ * (ZK_E_SHAPE) unless M is a multiple of 256                                                                         */
+#define ZK_TEST_SHORT_X 0x800
 /* LayerNorm(768): x (rows,768) -> out (rows,768) = hi (+ lo when nsplit is 3 or 2) of the output planes            */
 int zk_test_layernorm(zk_ctx* ctx, const float* x, const float* gamma, const float* beta, int32_t rows, float eps,
                       int32_t nsplit, float* out);

@@ -424,6 +424,19 @@ def test_gemm_c8_rows_beyond_m_never_reach_a_store(ctx):
             assert np.array_equal(clean, ctx.test_gemm(x, w, bias3[:N], epi, 2, resid=r0, tiled_in=tiled, poison_pad=True))
 
 
+def test_gemm_c8_launcher_enforces_the_padding_contract(ctx):
+    """zk_gemm_args::x_rows: x planes stated as M rows are refused unless M is a whole number of 256-row blocks"""
+    from zkast import lib
+    rng = np.random.default_rng(5)
+    w = rng.normal(0, 0.05, (768, 768)).astype(np.float32)
+    b = np.zeros(768, np.float32)
+    x = rng.normal(0, 1.0, (512, 768)).astype(np.float32)
+    ok = ctx.test_gemm(x, w, b, lib.EPI_STORE, 2, short_x=True)             # 512 = 2 x 256: nothing is read behind M
+    assert np.array_equal(ok, ctx.test_gemm(x, w, b, lib.EPI_STORE, 2))
+    with pytest.raises(lib.ZkError, match="refused"):
+        ctx.test_gemm(x[:300], w, b, lib.EPI_STORE, 2, short_x=True)
+
+
 @pytest.mark.parametrize("rows", [37, 256, 700])
 def test_layernorm_tiled_planes_equal_row_major(ctx, rows):
     rng = np.random.default_rng(rows)

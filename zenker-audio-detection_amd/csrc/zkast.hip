@@ -705,7 +705,7 @@ void* zk_ctx_stage_buf(zk_ctx* c, int which, size_t bytes) {
 // =====================================================================================================================
 extern "C" {
 
-const char* zk_version(void) { return "zkast 0.2 (gfx950)"; }
+const char* zk_version(void) { return "zkast 0.4 (gfx950)"; }
 
 int zk_create(int device_id, zk_ctx** out) {
   if (!out) return fail(nullptr, ZK_E_ARG, "out is NULL");
@@ -1345,7 +1345,8 @@ int zk_test_gemm(zk_ctx* c, const float* x, const float* w, const float* bias, i
   a.x_rowexp = dexp;
   a.M = M; a.N = N; a.K = K; a.o_hi = oh; a.o_lo = nsplit != ZK_F16 ? ol : nullptr; a.resid = dres; a.pos = dpos; a.lo_n_limit = N; a.lo_c8_from = 1 << 30;
   a.w_exp = w_exp;
-  a.x_rows = (int64_t)m_pad; a.x_tiled = tiled_in; a.o_tiled = tiled_out;
+  // ZK_TEST_SHORT_X: state the allocation as M rows only — the launcher must then refuse an M that is not a multiple of 256
+  a.x_rows = (epi_flags & ZK_TEST_SHORT_X) ? (int64_t)M : (int64_t)m_pad; a.x_tiled = tiled_in; a.o_tiled = tiled_out;
   if (nsplit == ZK_F16C8) {
     if (zk_launch_gemm_c8(a, epi, c->stream)) return fail(c, ZK_E_SHAPE, "zk_launch_gemm_c8 refused the launch");
   } else zk_launch_gemm(a, epi, nsplit, c->stream);

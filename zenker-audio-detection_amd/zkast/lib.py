@@ -21,7 +21,7 @@ CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 ZK_F16, ZK_F16C8, ZK_F16X3 = 1, 2, 3
 ZK_DT_F32, ZK_DT_F16, ZK_DT_BF16 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_PATCH = 0, 1, 2, 3
-TEST_TILED_IN, TEST_TILED_OUT, TEST_POISON_PAD = 0x100, 0x200, 0x400      # include/zkast.h: ZK_TEST_*
+TEST_TILED_IN, TEST_TILED_OUT, TEST_POISON_PAD, TEST_SHORT_X = 0x100, 0x200, 0x400, 0x800      # include/zkast.h: ZK_TEST_*
 COMPUTE_MODES = {"f16": ZK_F16, "f16c8": ZK_F16C8, "f16x3": ZK_F16X3, 1: ZK_F16, 2: ZK_F16C8, 3: ZK_F16X3}
 
 # every symbol include/zkast.h declares (tests/test_abi.py checks the .so exports exactly these)
@@ -505,7 +505,8 @@ class Context:
                   "zk_test_layernorm")
         return out
 
-    def test_gemm(self, x, w, bias, epi, nsplit, resid=None, pos=None, tiled_in=False, tiled_out=False, poison_pad=False):
+    def test_gemm(self, x, w, bias, epi, nsplit, resid=None, pos=None, tiled_in=False, tiled_out=False, poison_pad=False,
+                  short_x=False):
         x = np.ascontiguousarray(x, np.float32)
         w = np.ascontiguousarray(w, np.float32)
         bias = np.ascontiguousarray(bias, np.float32)
@@ -519,7 +520,7 @@ class Context:
         else:
             out = np.empty((M, N), np.float32)
         flags = (int(epi) | (TEST_TILED_IN if tiled_in else 0) | (TEST_TILED_OUT if tiled_out else 0)
-                 | (TEST_POISON_PAD if poison_pad else 0))
+                 | (TEST_POISON_PAD if poison_pad else 0) | (TEST_SHORT_X if short_x else 0))
         self._chk(self.lib.zk_test_gemm(self.h, x.ctypes.data, w.ctypes.data, bias.ctypes.data, M, N, K, flags,
                                         int(nsplit), None if pos is None else pos.ctypes.data, out.ctypes.data),
                   "zk_test_gemm")
