@@ -50,30 +50,9 @@ CLOCK_FILE = "r04_gemm_clock.json"         # in-kernel s_memtime / s_memrealtime
 # P·V as Vh·P + Vl·P (16 fp16 MFMAs, 512 cycles): 1 024 cycles against 512
 PASSES_PER_FLOP = {"f16c8": 2.0, "f16x3": 3.0, "f16": 1.0}
 ATTN_PASSES_PER_FLOP = {"f16c8": 2.0, "f16x3": 2.5, "f16": 1.0}
-import argparse
-import hashlib
-import json
-import os
-import signal
-import struct
-import sys
-import time
-import traceback
-
-import numpy as np
-
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "zenker-audio-detection_amd"))
-sys.path.insert(0, ROOT)
-
-FLOP_PER_WINDOW_STAGE = 261.03e9          # dense AST forward at S=1214
-PEAK_F16_DENSE = 2.5e15                   # MI355X_MICROARCH.md: BF16/FP16 MFMA dense peak
-TRAFFIC_FILE = "r04_pmc_traffic.json"      # rocprofv3 --pmc passes of this round (tools/pmc_traffic.py)
-CLOCK_FILE = "r04_gemm_clock.json"         # in-kernel s_memtime / s_memrealtime pair of a stamp build (tools/gemm_stamps.py)
-# matrix-pipe passes per algorithmic FLOP of each compute mode: f16c8 = one fp16 pass + one fp8 pass of
-# K' = 2K bytes at twice the rate = 2 fp16-pass-equivalents; f16x3 = 3 fp16 passes; attention = QK^T 1.5 + PV 2.0 over 2
-PASSES_PER_FLOP = {"f16c8": 2.0, "f16x3": 3.0, "f16": 1.0}
-ATTN_PASSES_PER_FLOP = {"f16c8": 1.75, "f16x3": 2.5, "f16": 1.0}
+# f16mix runs each kernel group of each encoder layer in f16x3 or f16c8 (zkast.lib.MIX_X3_GROUPS); its kernels are those two modes' kernels, timed
+# apart ("gemm_fc1" = the f16c8 launches, "gemm_fc1_x3" = the f16x3 ones), so a kernel's pass count is its own mode's
+KERNEL_MODE = lambda name, mode: ("f16x3" if name.endswith("_x3") else "f16c8") if mode == "f16mix" else mode  # noqa: E731
 
 
 def main():
@@ -84,7 +63,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step")
     ap.add_argument("--gate-rate", type=float, default=1.0, help="fraction of windows that go on to stage 2 (headline)")
     ap.add_argument("--micro-batch", type=int, default=0, help="0 = library default (auto)")
-    ap.add_argument("--mode", default="f16c8", choices=["f16c8", "f16x3", "f16"])
+    ap.add_argument("--mode", default=None, choices=["f16mix", "f16c8", "f16x3", "f16"],
+                    help="compute mode of the headline (default: zkast.lib.DEFAULT_COMPUTE_MODE, the cheapest mode that keeps "
+                         ">= 20 %% of the 1e-3 logit tolerance at configs[3] scale)")
+    ap.add_argument("--x3", default=None,
+                    help="f16mix only (exploration): what runs f16x3, e.g. '0' (layer 0), '0:qkv+att,1:mlp' (kernel groups of a layer: "
+                         "qkv, att, o, mlp); default zkast.lib.MIX_X3_GROUPS")
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary f16x3 / single-pass fp16 measurements")
     ap.add_argument("--no-sweep", action="store_true", help="skip the g = 0.5 / 0.1 gate-rate lines")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -124,6 +108,22 @@ def main():
 
     from zkast import ZkASTConfig, ZkASTForAudioClassification, lib, synth
     from zkast import dist as zdist
+
+    if args.mode is None:
+        args.mode = lib.DEFAULT_COMPUTE_MODE
+    x3_groups = lib.MIX_X3_GROUPS
+    if args.x3 is not None:
+        x3_groups = {}
+        for item in (v for v in args.x3.split(",") if v != ""):
+            layer, _, groups = item.partition(":")
+            x3_groups[int(layer)] = tuple(groups.split("+")) if groups else lib.LAYER_GROUPS
+
+    def apply_mode(models, mode):
+        for m in models:
+            if mode == "f16mix" and args.x3 is not None:
+                m.set_layer_modes(lib.mix_layer_modes(x3_groups))
+            else:
+                m.set_compute_mode(mode)
 
     ctx = lib.get_context(local_rank)
     ctx.set_micro_batch(args.micro_batch)
@@ -193,6 +193,7 @@ def main():
                                      device=local_rank, fx_mean=S1[0], fx_std=S1[1])
     m2 = ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd2, stage=1, compute_mode=args.mode,
                                      device=local_rank, fx_mean=S2[0], fx_std=S2[1])
+    apply_mode((m1, m2), args.mode)
     ctx.ast_forward(0, None, None, B, s1_logits)
     p_sw = ctx.softmax(s1_logits)[:, 1].astype(np.float32)
     assert (p_sw > 0.5).all()
@@ -244,9 +245,28 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         prof = ctx.prof_end() if profile else None
+        state["dt_local"] = dt
         return max_over_ranks(dt), prof
 
     dt, prof = timed(args.steps, args.warmup, profile=True)
+    # ---- N > 1: the run describes itself — what communicator every rank saw, what the two logit gathers of a step cost
+    #      (HIP events on the context's stream around ncclAllGather: the library's "allgather" profile class) and how far the
+    #      ranks' own step times lie apart — so that a SCALE line needs no second run to be read ----
+    multi = None
+    if world > 1:
+        ag_ms, ag_n, _ = prof["allgather"]
+        mine = json.dumps({"rank": rank, "rccl_rank": rccl_rank, "rccl_world": rccl_world, "device": local_rank,
+                           "ms_per_step": state["dt_local"] / args.steps * 1e3,
+                           "allgather_calls_per_step": ag_n / args.steps, "allgather_ms_per_step": ag_ms / args.steps,
+                           "stage2_windows": int(sw_cnt[0])}).encode().ljust(384)
+        recs = [json.loads(bytes(b).decode()) for b in gather_bytes(mine)]
+        steps_ms = [r["ms_per_step"] for r in recs]
+        multi = {"per_rank": recs, "ms_per_step_min": min(steps_ms), "ms_per_step_max": max(steps_ms),
+                 "ms_per_step_spread_frac": (max(steps_ms) - min(steps_ms)) / max(steps_ms),
+                 "allgather_ms_per_step_max": max(r["allgather_ms_per_step"] for r in recs),
+                 "note": "allgather = the RCCL collective of zk_allgather_logits alone (2 per step, HIP events on the context's stream, "
+                         "the wait for the slowest peer included; 0 calls under the gloo fallback); the byte gathers used as barriers "
+                         "are not counted"}
     K = int(sw_cnt[0])
     windows = world * B * args.steps
     value = windows / dt
@@ -254,7 +274,9 @@ def main():
     # ---- per-kernel roofline from the HIP-event timings of the timed region (rank 0; events are recorded by the
     #      library on the context's own stream, the stream its kernels are launched on) ----
     roof_all = {}
-    for name in ("gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention"):
+    MATRIX = ("gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention",
+              "gemm_qkv_x3", "gemm_o_x3", "gemm_fc1_x3", "gemm_fc2_x3", "attention_x3")
+    for name in MATRIX:
         ms, cnt, fl = prof[name]                               # fl = algorithmic FLOPs EXECUTED (exact pruning applied)
         if cnt:
             roof_all[name] = dict(ms_per_launch=ms / cnt, launches=cnt, tflops=fl / (ms * 1e-3) / 1e12,
@@ -271,9 +293,9 @@ def main():
         lm.update(algorithmic_bytes_per_launch=lm_bytes, gb_per_s=lm_bytes / (lm["ms_per_launch"] * 1e-3) / 1e9,
                   frac_of_hbm_peak=lm_bytes / (lm["ms_per_launch"] * 1e-3) / 8.0e12,
                   note="fp64 FFT in LDS: VALU / barrier-bound, not HBM-bound; 0.06 % of the step")
-    executed = sum(prof[n][2] for n in ("gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention"))
+    executed = sum(prof[n][2] for n in MATRIX)
     dom = max((k for k in roof_all if "tflops" in roof_all[k]), key=lambda k: roof_all[k]["share"])
-    passes = (ATTN_PASSES_PER_FLOP if dom == "attention" else PASSES_PER_FLOP)[args.mode]
+    passes = (ATTN_PASSES_PER_FLOP if dom.startswith("attention") else PASSES_PER_FLOP)[KERNEL_MODE(dom, args.mode)]
     frac = roof_all[dom]["tflops"] * 1e12 / PEAK_F16_DENSE
     roofline = {"kernel": dom, "bound": "mfma", "achieved": roof_all[dom]["tflops"], "peak": PEAK_F16_DENSE / 1e12,
                 "unit": "TFLOP/s", "frac": frac, "traffic": None,
@@ -292,7 +314,7 @@ def main():
         so_hash = hashlib.sha256(open(lib.LIB_PATH, "rb").read()).hexdigest()
         key = {"gemm_fc1": "gemm_fc1(gelu)", "gemm_qkv": "gemm_qkv(store)", "gemm_fc2": "gemm_fc2(resid)",
                "gemm_o": "gemm_o(resid)", "attention": "attention"}[dom]
-        if tr.get("libzkast_sha256") == so_hash and args.mode == "f16c8":
+        if tr.get("libzkast_sha256") == so_hash and KERNEL_MODE(dom, args.mode) == "f16c8":
             roofline["traffic"] = tr["kernels"][key]["hbm_bytes_per_launch_corrected"]
             roofline["mfma_util"] = tr["kernels"][key].get("mfma_util")      # SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES)
             roofline["traffic_source"] = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc, separate passes, same libzkast.so)"
@@ -316,6 +338,8 @@ def main():
                    "micro_batch": args.micro_batch, "weights": "synthetic splitmix64 'wide' set (seeds 21/22), stage-1 "
                    f"swallow bias shifted by {shift:+.3f} so that thr1 alone sets the gate rate",
                    "parallelism": f"window-sharded x{world}, {collective}" if world > 1 else "single GPU",
+                   "compute_mode": args.mode + (f" (f16x3 for {({k: list(v) for k, v in x3_groups.items()})} = layer: kernel groups, f16c8 elsewhere)"
+                                                if args.mode == "f16mix" else ""),
                    "rccl_world": rccl_world if use_rccl else (1 if world == 1 else 0),
                    "collective_fallback": bool(world > 1 and not use_rccl)},
         "roofline": roofline,
@@ -323,10 +347,14 @@ def main():
                                 "achieved_tflops_per_gpu": e2e_flops / 1e12, "frac_of_f16_dense_peak": e2e_flops / PEAK_F16_DENSE,
                                 "executed_gflop_per_window_stage": executed / (args.steps * (B + K)) / 1e9,
                                 "executed_tflops_per_gpu": executed / dt / 1e12,
-                                "note": "executed = exact last-layer pruning applied (tokens 0/1 only feed the head); "
-                                        "f16c8 issues 2 (f16x3: 3) matrix-pipe passes per GEMM FLOP counted here once"},
+                                "frac_of_f16_dense_peak_executed": executed / dt / PEAK_F16_DENSE,
+                                "note": "executed = the exact shortcuts applied (last-layer pruning: tokens 0/1 only feed the head; layer-0 "
+                                        "constant rows); never claim more than executed / peak (SURVEY 8d).  f16c8 issues 2 (f16x3: 3) "
+                                        "matrix-pipe passes per GEMM FLOP counted here once"},
         "kernels": roof_all,
     }
+    if multi is not None:
+        out["multi_gpu"] = multi
 
     # ---- gate-rate sweep (g in {0.1, 0.5, 1.0}); windows/s counts stage-1 windows, as the headline ----
     def gate_sweep():
@@ -351,17 +379,21 @@ def main():
         ref1 = s1_logits.copy()
         nsec = max(1, args.steps // 2)
         try:
-            for key, mode, note in (("x3_mode", "f16x3", "(hi,lo) fp16 pairs, 3 MFMA passes; also meets the 1e-3 logit tolerance"),
+            for key, mode, note in (("mix_mode", "f16mix", "f16x3 / f16c8 per layer and kernel group (zkast.lib.MIX_X3_GROUPS)"),
+                                    ("c8_mode", "f16c8", "fp16 pass + one fp8 correction pass in every layer: inside 1e-3 on the golden sets, "
+                                                         "without margin at configs[3] scale on the input-sensitive set"),
+                                    ("x3_mode", "f16x3", "(hi,lo) fp16 pairs, 3 MFMA passes; also meets the 1e-3 logit tolerance"),
                                     ("fast_mode", "f16", "single fp16 MFMA pass; exceeds the 1e-3 logit tolerance, not the headline")):
+                if mode == args.mode:
+                    continue
                 m1.set_compute_mode(mode)
                 m2.set_compute_mode(mode)
                 dtf, _ = timed(nsec, 1)
                 err = float(np.abs(s1_logits - ref1).max())
                 out[key] = {"dtype": mode, "value": world * B * nsec / dtf, "unit": "windows/s",
-                            "stage1_logit_max_abs_diff_vs_f16c8": err, "note": note}
+                            f"stage1_logit_max_abs_diff_vs_{args.mode}": err, "note": note}
         finally:
-            m1.set_compute_mode(args.mode)
-            m2.set_compute_mode(args.mode)
+            apply_mode((m1, m2), args.mode)
 
     # ---- BASELINE.json configs[1] as an extra line: batch 256, stage-1 only (log-mel + forward), all modes ----
     def config1():
@@ -376,10 +408,10 @@ def main():
             return n256 * reps / (time.perf_counter() - t0)
         cfg1 = {"workload": "configs[1]: batch=256 windows, stage-1 only (log-mel + AST forward)", "unit": "windows/s"}
         try:
-            for md in ("f16c8", "f16x3", "f16"):
+            for md in ("f16mix", "f16c8", "f16x3", "f16"):
                 m1.set_compute_mode(md); cfg1[md] = stage1_b256()
         finally:
-            m1.set_compute_mode(args.mode)
+            apply_mode((m1,), args.mode)
         out["config1_stage1_b256"] = cfg1
 
     # ---- load_audio line (HBM GB/s of the 48 -> 16 kHz polyphase kernel, reported separately): the product's
@@ -423,18 +455,18 @@ def main():
     def parity_gpu():
         try:
             for st, sd, fxs in ((0, sens1, S1), (1, sens2, S2)):
-                ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd, stage=st, compute_mode=args.mode,
-                                            device=local_rank, fx_mean=fxs[0], fx_std=fxs[1])
+                apply_mode((ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd, stage=st, compute_mode=args.mode,
+                                                        device=local_rank, fx_mean=fxs[0], fx_std=fxs[1]),), args.mode)
             ctx.logmel(audio, n_samples, 0, hop, win, n_cpu)
             for st in (0, 1):
                 lg = np.empty((n_cpu, 2), np.float32)
                 ctx.ast_forward(st, None, None, n_cpu, lg)
                 gpu_sens[st] = lg
         finally:      # the headline's weights go back (later legs and a re-run see the timed configuration)
-            ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd1s, stage=0, compute_mode=args.mode,
-                                        device=local_rank, fx_mean=S1[0], fx_std=S1[1])
-            ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd2, stage=1, compute_mode=args.mode,
-                                        device=local_rank, fx_mean=S2[0], fx_std=S2[1])
+            apply_mode((ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd1s, stage=0, compute_mode=args.mode,
+                                                    device=local_rank, fx_mean=S1[0], fx_std=S1[1]),
+                        ZkASTForAudioClassification(ZkASTConfig(num_labels=2), sd2, stage=1, compute_mode=args.mode,
+                                                    device=local_rank, fx_mean=S2[0], fx_std=S2[1])), args.mode)
 
     # ---- CPU baseline: the build's own fp32 restatement on torch-CPU operators + the numpy log-mel
     #      (oracle/ast_torch_cpu.py, pinned against the golden transformers logits in tests/test_oracle.py) on this box's
@@ -518,7 +550,7 @@ def main():
     single = rank == 0 and world == 1 and not args.headline_only
     try:
         leg("gate_sweep", lambda: gate_sweep(), need_s=15, when=not args.no_sweep)
-        leg("x3_fast_modes", lambda: other_modes(), need_s=15, when=not args.no_fast and args.mode == "f16c8")
+        leg("other_modes", lambda: other_modes(), need_s=20, when=not args.no_fast and args.mode in ("f16c8", "f16mix"))
         leg("config1_stage1_b256", lambda: config1(), need_s=10, when=single)
         leg("resample_48k_to_16k", lambda: resample_leg(), need_s=10, when=single)
         leg("parity_gpu_sens", lambda: parity_gpu(), need_s=10, when=single and not args.no_cpu)

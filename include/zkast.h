@@ -38,7 +38,11 @@ enum {
   ZK_F16C8 = 2, /* fp16 pass + ONE fp8 (e4m3) pass that carries both split-correction products (they are 2^-11 of
                    the result, so 4 significant bits suffice): fp32-grade products at 2 matrix-pipe passes;
                    meets the 1e-3 tolerance (measured ~1e-4)                                                    */
-  ZK_F16X3 = 3  /* (hi,lo) fp16 operand pairs, 3 MFMA passes: fp32-equivalent products; meets the 1e-3 tolerance */
+  ZK_F16X3 = 3, /* (hi,lo) fp16 operand pairs, 3 MFMA passes: fp32-equivalent products; meets the 1e-3 tolerance */
+  ZK_F16MIX = 4 /* ZK_F16X3 or ZK_F16C8 per encoder layer and kernel group (layers only exchange the fp32 residual stream,
+                   producers write the plane format their consumer reads).  The default assignment is the cheapest one
+                   measured to keep >= 20 % of the 1e-3 tolerance on a 3 599-window recording of the input-sensitive
+                   weight set; zk_model_set_layer_modes sets another                                    */
 };
 
 /* tensor dtypes accepted by zk_model_load */
@@ -85,6 +89,12 @@ const char* zk_version(void);
 int zk_model_load(zk_ctx* ctx, int stage, const zk_tensor_desc* tensors, int32_t n_tensors, const zk_ast_config* cfg,
                   float fx_mean, float fx_std, int32_t compute_mode);
 int zk_model_set_compute_mode(zk_ctx* ctx, int stage, int32_t compute_mode);
+/* one compute mode (ZK_F16 / ZK_F16C8 / ZK_F16X3) per encoder layer (n = num_hidden_layers entries), or per kernel group of
+ * each layer (n = 4 * num_hidden_layers: [layer][QKV GEMM, QK^T of attention, O projection, MLP = FC1 + FC2]); the model's
+ * mode becomes ZK_F16MIX.  ZK_F16C8 for QK^T needs the ZK_F16C8 QKV GEMM of that layer (its epilogue writes k's c8 plane).
+ * The reference has one dtype per model (model.to(DEVICE), src/test_long_audio_windows_2stage.py:96); this is the knob
+ * that trades matrix-pipe passes against the logit tolerance where the error is made.                              */
+int zk_model_set_layer_modes(zk_ctx* ctx, int stage, const int32_t* modes, int32_t n);
 /* the extractor statistics used when a forward runs from the feature slot (fx.mean / fx.std of that stage) */
 int zk_model_set_fx(zk_ctx* ctx, int stage, float fx_mean, float fx_std);
 
@@ -171,7 +181,11 @@ int zk_audio_get(zk_ctx* ctx, float* out /*host|device*/, int64_t* n_samples);
 /* ---- introspection / measurement ---------------------------------------------------------------------------- */
 /* per-kernel-class HIP-event timing over the calls made since zk_prof_begin (on the context's stream).
  * zk_prof_get: name in {"gemm_qkv","gemm_o","gemm_fc1","gemm_fc2","gemm_patch","attention","layernorm","logmel",
- * "embed","head","wav_decode","resample"} -> accumulated milliseconds and launch count.                           */
+ * "embed","head","wav_decode","resample","allgather"} -> accumulated milliseconds and launch count
+ * ("allgather": the RCCL collective of zk_allgather_logits alone, without its staging copies — it includes the wait for the
+ * slowest peer; the byte gathers are not counted;
+ * inside a ZK_F16MIX model the layers that run ZK_F16X3 are other kernels and count apart: "gemm_qkv_x3","gemm_o_x3",
+ * "gemm_fc1_x3","gemm_fc2_x3","attention_x3"). */
 int zk_prof_begin(zk_ctx* ctx);
 int zk_prof_end(zk_ctx* ctx);
 int zk_prof_get(zk_ctx* ctx, const char* name, double* ms, int64_t* launches);

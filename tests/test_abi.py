@@ -87,3 +87,43 @@ def test_one_hip_runtime_image_whatever_the_import_order():
         r = subprocess.run([sys.executable, "-c", body.format(first=first, second=second)], capture_output=True, text=True,
                            timeout=300)
         assert r.returncode == 0 and r.stdout.startswith("ok"), (first, r.stdout, r.stderr[-2000:])
+
+
+def _run_py(code, env_extra):
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    env["PYTHONPATH"] = os.path.join(ROOT, "zenker-audio-detection_amd") + os.pathsep + env.get("PYTHONPATH", "")
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_rccl_override_that_does_not_load_is_an_error_with_a_reason(handle):
+    """$ZKAST_RCCL_LIB is an explicit override: a file that cannot be loaded must come back as an error code and a message
+    (round 4: the path crashed on a second dlerror() call) — and must not fall through to some other RCCL."""
+    r = _run_py("from zkast import lib\n"
+                "try:\n    lib.comm_unique_id()\n    print('LOADED')\n"
+                "except lib.ZkError as e:\n    print('ZKERROR', e)\n", {"ZKAST_RCCL_LIB": "/nonexistent/librccl-missing.so"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ZKERROR" in r.stdout and "/nonexistent/librccl-missing.so" in r.stdout and "LOADED" not in r.stdout, r.stdout
+
+
+def test_hip_runtime_override_wins_or_fails_loudly(handle):
+    """$ZKAST_HIP_LIB ranks first (round 4 ranked it below a torch wheel's runtime); a path that does not load raises."""
+    r = _run_py("from zkast import lib\n"
+                "try:\n    lib.load_library()\n    print('LOADED', lib.HIP_RUNTIME_PATH)\n"
+                "except lib.ZkError as e:\n    print('ZKERROR', e)\n", {"ZKAST_HIP_LIB": "/nonexistent/libamdhip64.so"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ZKERROR" in r.stdout and "ZKAST_HIP_LIB=/nonexistent/libamdhip64.so" in r.stdout, r.stdout
+    sysrt = "/opt/rocm/lib/libamdhip64.so.7"
+    if os.path.exists(sysrt):
+        r = _run_py("from zkast import lib\nlib.load_library()\nprint('LOADED', lib.HIP_RUNTIME_PATH)\n", {"ZKAST_HIP_LIB": sysrt})
+        assert r.returncode == 0 and f"LOADED {sysrt}" in r.stdout, (r.stdout, r.stderr[-2000:])
+        # another runtime already mapped: refuse instead of loading a second one
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        wheel_rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else ""
+        if os.path.exists(wheel_rt) and os.path.realpath(wheel_rt) != os.path.realpath(sysrt):
+            r = _run_py(f"import ctypes\nctypes.CDLL({wheel_rt!r}, mode=ctypes.RTLD_GLOBAL)\nfrom zkast import lib\n"
+                        "try:\n    lib.load_library()\n    print('LOADED')\n"
+                        "except lib.ZkError as e:\n    print('ZKERROR', e)\n", {"ZKAST_HIP_LIB": sysrt})
+            assert "ZKERROR" in r.stdout and "already mapped" in r.stdout, (r.stdout, r.stderr[-2000:])

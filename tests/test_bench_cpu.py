@@ -7,6 +7,7 @@ These tests start a FRESH interpreter for that reason.
 """
 import json
 import os
+import re
 import subprocess
 import sys
 import textwrap
@@ -119,3 +120,20 @@ def test_bench_leg_guard_records_errors_and_still_prints(tmp_path):
     assert line["cpu_baseline"]["error"].startswith("TypeError")
     assert line["legs"]["cpu_baseline"].startswith("FAILED") and line["legs"]["after"].startswith("ok")
     assert line["legs"]["late"].startswith("skipped")
+
+
+def test_bench_constants_are_defined_once_and_match_the_design():
+    """round 4: a bad merge duplicated bench.py's header block and the two copies disagreed on the attention pass count"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for name in ("FLOP_PER_WINDOW_STAGE", "PEAK_F16_DENSE", "PASSES_PER_FLOP", "ATTN_PASSES_PER_FLOP", "TRAFFIC_FILE", "CLOCK_FILE"):
+        assert len(re.findall(rf"^{name}\s*=", src, flags=re.M)) == 1, name
+    assert src.count("import argparse") == 1
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    assert bench.FLOP_PER_WINDOW_STAGE == 261.03e9 and bench.PEAK_F16_DENSE == 2.5e15      # SURVEY.md 8(d), MI355X_MICROARCH.md
+    assert bench.PASSES_PER_FLOP["f16c8"] == 2.0 and bench.PASSES_PER_FLOP["f16x3"] == 3.0 and bench.PASSES_PER_FLOP["f16"] == 1.0
+    # attention, per 64-key tile and wave: 512 matrix-pipe cycles for one pass; f16c8 1 024 (QK^T 8 fp16 + 4 fp8 = 512, Vh·P + Vl·P = 512)
+    assert bench.ATTN_PASSES_PER_FLOP == {"f16c8": 2.0, "f16x3": 2.5, "f16": 1.0}
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert "261.03" in design and "2.5 PFLOP/s" in design

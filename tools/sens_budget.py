@@ -43,9 +43,14 @@ def lin(x, w, b, mode):
     return F.linear(xh, wh) + corr + b
 
 
-def forward(m, x, gemm="f32", qk="f32", p="f32", v="f32"):
+def forward(m, x, gemm="f32", qk="f32", p="f32", v="f32", layers=None, other=None):
+    """layers: the encoder layers the rounding modes apply to (None = all); the other layers run `other` (a dict of the same
+    keywords, default: everything fp32) — per-layer budgets and the mixed c8 / x3 modes."""
     B = x.shape[0]
-    gm = gemm if isinstance(gemm, dict) else {k: gemm for k in ("patch", "qkv", "o", "fc1", "fc2")}
+    mk = lambda g: g if isinstance(g, dict) else {k: g for k in ("patch", "qkv", "o", "fc1", "fc2")}
+    sel = (mk(gemm), qk, p, v)
+    oth = (mk((other or {}).get("gemm", "f32")), (other or {}).get("qk", "f32"), (other or {}).get("p", "f32"), (other or {}).get("v", "f32"))
+    gm = sel[0]
     gemm = gm.get("patch", "f32")
     with torch.inference_mode():
         h = F.conv2d(x.unsqueeze(1).transpose(2, 3), m.conv_w, m.conv_b, stride=(orc.FSTRIDE, orc.TSTRIDE)) if gemm == "f32" else None
@@ -55,7 +60,8 @@ def forward(m, x, gemm="f32", qk="f32", p="f32", v="f32"):
         else:
             h = h.flatten(2).transpose(1, 2)
         h = torch.cat([m.cls.expand(B, -1, -1), m.dist.expand(B, -1, -1), h], dim=1) + m.pos
-        for L in m.layers:
+        for li, L in enumerate(m.layers):
+            gm, qk, p, v = sel if (layers is None or li in layers) else oth
             y = F.layer_norm(h, (768,), L["ln1"][0], L["ln1"][1], orc.LN_EPS)
             qkv = lin(y, L["qkv"][0], L["qkv"][1], gm.get("qkv", "f32")).view(B, orc.SEQ, 3, 12, 64).permute(2, 0, 3, 1, 4)
             q, k, vv = qkv[0] * 0.125, qkv[1], qkv[2]
@@ -116,7 +122,52 @@ def forward(m, x, gemm="f32", qk="f32", p="f32", v="f32"):
         return F.linear(z, *m.head).numpy()
 
 
+def stats(out, ref):
+    err = np.abs(out - ref).max(axis=1)
+    return f"rms {np.sqrt((err ** 2).mean()):.2e}  max {err.max():.2e}"
+
+
+def per_layer():
+    """PER_LAYER=n: rms / max logit error over the first n windows of the test recording for each (layer, source) alone, and
+    for the mixed modes "first k layers in x3, the others c8"."""
+    n = int(os.environ["PER_LAYER"])
+    seed = int(os.environ.get("SEED", "31"))
+    sd = synth.make_ast_weights(seed, "sens")
+    rec = synth.synth_recording(7, 16000 + (n - 1) * 8000)
+    st = (-1.1509622, 3.5340312) if seed == 31 else (-6.5, 2.75)
+    x = torch.from_numpy(orc.extract_features(orc.window_audio(rec), *st))
+    m = tcpu.TorchAST(sd)
+    ref = forward(m, x)
+    dev_c8 = dict(gemm=dict(patch="x3", qkv="c8", o="c8", fc1="c8", fc2="c8"), qk="c8", p="thr2")
+    dev_x3 = dict(gemm="x3", qk="x3", p="thr2")
+    print(f"{n} windows; device f16c8: {stats(forward(m, x, **dev_c8), ref)}; device f16x3: {stats(forward(m, x, **dev_x3), ref)}", flush=True)
+    what = os.environ.get("WHAT", "layers,mixed").split(",")
+    if "layers" in what:
+        for li in range(12):
+            row = [f"layer {li:2d}"]
+            for name, kw in (("gemm c8", dict(gemm=dict(qkv="c8", o="c8", fc1="c8", fc2="c8"))), ("qk c8", dict(qk="c8")), ("P f16", dict(p="thr2"))):
+                row.append(f"{name}: {stats(forward(m, x, layers={li}, **kw), ref)}")
+            print("   ".join(row), flush=True)
+    if "mixed" in what:
+        for k in (1, 2, 3, 4, 6, 8):
+            out = forward(m, x, layers=set(range(k)), other=dev_c8, **dict(dev_x3, gemm=dict(patch="x3", qkv="x3", o="x3", fc1="x3", fc2="x3")))
+            print(f"first {k} layers x3, rest c8: {stats(out, ref)}", flush=True)
+        for k in (8, 6, 4):
+            out = forward(m, x, layers=set(range(k, 12)), other=dev_c8, **dev_x3)
+            print(f"layers {k}..11 x3, rest c8: {stats(out, ref)}", flush=True)
+    if "kinds" in what:
+        for kinds in (("qkv",), ("o",), ("fc1",), ("fc2",), ("qkv", "fc2"), ("qkv", "o"), ("fc1", "fc2")):
+            g = dict(patch="x3", qkv="c8", o="c8", fc1="c8", fc2="c8")
+            for kk in kinds: g[kk] = "x3"
+            print(f"c8 but {kinds} x3: {stats(forward(m, x, gemm=g, qk='c8', p='thr2'), ref)}", flush=True)
+        print(f"c8 with QK x3: {stats(forward(m, x, gemm=dev_c8['gemm'], qk='x3', p='thr2'), ref)}", flush=True)
+        print(f"c8 with P hi+lo: {stats(forward(m, x, gemm=dev_c8['gemm'], qk='c8', p='f16x2'), ref)}", flush=True)
+        print(f"x3 with P hi+lo: {stats(forward(m, x, gemm='x3', qk='x3', p='f16x2'), ref)}", flush=True)
+
+
 def main():
+    if os.environ.get("PER_LAYER"):
+        return per_layer()
     idx = [int(a) for a in sys.argv[1:]] or [20, 53, 85, 55, 3, 100]
     seed = int(os.environ.get("SEED", "31"))
     sd = synth.make_ast_weights(seed, "sens")

@@ -13,7 +13,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # them in AGPRs and the attention softmax pays ~150 v_accvgpr_read/write per key tile.
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
 PRODUCT="gemm gemm_c8 attention layernorm embed head logmel misc comm zkast"
-PROBES="gemm_c8_v1 gemm_c6 probe probe_c6"
+PROBES="gemm_c8_v1 probe"
 SRCS="$PRODUCT"
 [ "${ZK_PROBES:-0}" = "1" ] && SRCS="$PRODUCT $PROBES"
 pids=()

@@ -7,8 +7,9 @@
 // RCCL is dlopen()ed on first use: libzkast.so has no link-time dependency on it and single-GPU use never loads it.
 // It must be the RCCL that belongs to the HIP runtime this process already uses (libzkast.so itself binds to whichever
 // libamdhip64 the host loaded, see zkast/lib.py): a PyTorch wheel ships its own libamdhip64.so + librccl.so, and an RCCL
-// from another ROCm tree would pull a SECOND HIP / HSA runtime into the process.  So the first candidate is the librccl
-// that lies next to the runtime `hipStreamSynchronize` resolved to (dladdr), then $ZKAST_RCCL_LIB, then the system names.
+// from another ROCm tree would pull a SECOND HIP / HSA runtime into the process.  Order: $ZKAST_RCCL_LIB when set — an
+// explicit override is the ONLY candidate, a file that does not load is an error, never a silent fall-through to another
+// RCCL — else the librccl that lies next to the runtime `hipStreamSynchronize` resolved to (dladdr), then the system names.
 #include "../../include/zkast.h"
 #include "zk_common.h"
 
@@ -25,6 +26,8 @@ int zk_ctx_device(zk_ctx* c);
 int zk_ctx_fail(zk_ctx* c, int code, const char* msg);
 void** zk_ctx_comm_slot(zk_ctx* c);      // opaque per-context pointer owned by this file
 void* zk_ctx_stage_buf(zk_ctx* c, int which, size_t bytes);      // device staging (which = 0 send, 1 recv); NULL on failure
+void* zk_ctx_prof_open_allgather(zk_ctx* c);      // zk_prof_* class "allgather": HIP events on the context's stream (NULL: not profiling)
+void zk_ctx_prof_close(void* scope);
 
 namespace {
 
@@ -46,9 +49,16 @@ struct RcclApi {
     auto attempt = [&](const std::string& name) {
       if (handle || name.empty()) return;
       handle = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
-      if (handle) path = name; else tried += (tried.empty() ? "" : ", ") + name;
+      if (handle) { path = name; return; }
+      const char* why = dlerror();      // read ONCE: dlerror() clears the message it returns
+      tried += (tried.empty() ? "" : "; ") + name + ": " + (why ? why : "?");
     };
-    if (const char* e = getenv("ZKAST_RCCL_LIB")) attempt(e);
+    if (const char* e = getenv("ZKAST_RCCL_LIB")) {
+      if (*e) {
+        attempt(e);
+        if (!handle) { err = "RCCL not loaded from $ZKAST_RCCL_LIB (" + tried + ")"; return false; }
+      }
+    }
     Dl_info info;
     memset(&info, 0, sizeof info);
     if (dladdr((const void*)&hipStreamSynchronize, &info) && info.dli_fname) {      // directory of the HIP runtime in use
@@ -62,7 +72,7 @@ struct RcclApi {
     }
     attempt("librccl.so.1");
     attempt("librccl.so");
-    if (!handle) { err = "RCCL not found (tried " + tried + "): " + (dlerror() ? dlerror() : "?"); return false; }
+    if (!handle) { err = "RCCL not found (tried " + tried + ")"; return false; }
 #define ZK_SYM(field, sym) field = (decltype(field))dlsym(handle, sym); if (!field) { err = std::string("RCCL lacks ") + sym; handle = nullptr; return false; }
     ZK_SYM(GetUniqueId, "ncclGetUniqueId")
     ZK_SYM(CommInitRank, "ncclCommInitRank")
@@ -94,7 +104,7 @@ bool on_device(const void* p) {
 }
 
 // every rank contributes `bytes`; recv holds world*bytes.  Host pointers are staged through the context's buffers.
-int allgather_bytes(zk_ctx* c, const void* send, size_t bytes, void* recv) {
+int allgather_bytes(zk_ctx* c, const void* send, size_t bytes, void* recv, bool timed) {
   Comm* cm = (Comm*)*zk_ctx_comm_slot(c);
   hipStream_t s = zk_ctx_stream(c);
   if (!cm || !cm->comm) {      // no communicator: a world of one
@@ -118,7 +128,11 @@ int allgather_bytes(zk_ctx* c, const void* send, size_t bytes, void* recv) {
     drecv = zk_ctx_stage_buf(c, 1, bytes * (size_t)cm->world);
     if (!drecv) return ZK_E_HIP;
   }
+  // the collective alone (staging copies are outside the bracket); only the logit gathers count, not the byte gathers the
+  // host code uses as barriers — those absorb the ranks' skew by design
+  void* scope = timed ? zk_ctx_prof_open_allgather(c) : nullptr;
   const int rc = g_rccl.AllGather(dsend, drecv, bytes, RCCL_CHAR, cm->comm, s);
+  zk_ctx_prof_close(scope);
   if (rc) return rfail(c, "ncclAllGather", rc);
   if (!rdev && hipMemcpyAsync(recv, drecv, bytes * (size_t)cm->world, hipMemcpyDeviceToHost, s) != hipSuccess)
     return zk_ctx_fail(c, ZK_E_HIP, "D2H copy failed");
@@ -132,7 +146,7 @@ extern "C" {
 
 int zk_comm_unique_id(void* out128) {
   if (!out128) return ZK_E_ARG;
-  if (!g_rccl.load()) return ZK_E_STATE;
+  if (!g_rccl.load()) return zk_ctx_fail(nullptr, ZK_E_STATE, g_rccl.err.c_str());      // zk_last_error(NULL) holds the reason
   rccl_uid_t id;
   if (g_rccl.GetUniqueId(&id)) return ZK_E_HIP;
   memcpy(out128, &id, sizeof id);
@@ -182,12 +196,12 @@ int zk_comm_info(zk_ctx* c, int32_t* rank, int32_t* world) {
 int zk_allgather_logits(zk_ctx* c, const float* local, int32_t rows_per_rank, int32_t cols, float* all) {
   if (!c || !local || !all) return ZK_E_ARG;
   if (rows_per_rank < 0 || cols < 1) return zk_ctx_fail(c, ZK_E_ARG, "zk_allgather_logits: bad shape");
-  return allgather_bytes(c, local, (size_t)rows_per_rank * cols * sizeof(float), all);
+  return allgather_bytes(c, local, (size_t)rows_per_rank * cols * sizeof(float), all, true);
 }
 
 int zk_comm_allgather_bytes(zk_ctx* c, const void* send, int64_t bytes, void* recv) {
   if (!c || bytes < 0 || (bytes && (!send || !recv))) return ZK_E_ARG;
-  return allgather_bytes(c, send, (size_t)bytes, recv);
+  return allgather_bytes(c, send, (size_t)bytes, recv, false);
 }
 
 }  // extern "C"

@@ -79,9 +79,44 @@ struct LayerW {
   WMat wqkv, wo, w1, w2;
 };
 
+// ZK_F16MIX: one nibble per encoder layer (layer l = bits 4l .. 4l+3: QKV GEMM, QK^T, O projection, MLP); a set bit runs that
+// kernel group in the 3-pass ZK_F16X3 arithmetic, a clear one in ZK_F16C8 (chosen on the input-sensitive
+// weight set so that a configs[3]-sized recording keeps >= 20 % of the 1e-3 logit tolerance)
+#ifndef ZK_MIX_X3_MASK
+#define ZK_MIX_X3_MASK 0xFull
+#endif
+struct LayerMode { int qkv, att, o, mlp; };
+// attention reads k's lo plane as c8 byte pairs only when the ZK_F16C8 QKV epilogue wrote them, and any lo plane only if
+// the QKV GEMM wrote one
+inline bool layer_mode_ok(const LayerMode& m) {
+  auto known = [](int v) { return v == ZK_F16 || v == ZK_F16C8 || v == ZK_F16X3; };
+  if (!known(m.qkv) || !known(m.att) || !known(m.o) || !known(m.mlp)) return false;
+  if (m.att == ZK_F16C8 && m.qkv != ZK_F16C8) return false;
+  if (m.att == ZK_F16X3 && m.qkv == ZK_F16) return false;
+  return true;
+}
 struct StageModel {
   bool loaded = false;
-  int mode = ZK_F16X3;
+  int mode = ZK_F16X3;            // what the caller asked for (ZK_F16MIX: see layer_mode)
+  // the mode each kernel group of each encoder layer runs in (ZK_F16 / ZK_F16C8 / ZK_F16X3): the fused QKV GEMM, attention's
+  // QK^T, the O projection, the MLP (FC1 + FC2 share a mode: FC1's epilogue writes FC2's operand planes).  Layers only
+  // exchange the fp32 residual stream and every producer writes the plane format its consumer reads, so any assignment
+  // that passes layer_modes_ok() is a valid forward (zk_model_set_layer_modes)
+  LayerMode layer_mode[ZK_LAYERS];
+  // mode of everything outside the encoder layers (the patch embedding): ZK_F16MIX counts as ZK_F16C8
+  int base_mode() const { return mode == ZK_F16MIX ? ZK_F16C8 : mode; }
+  bool any_split() const {
+    for (int l = 0; l < n_layers; ++l) { const LayerMode& m = layer_mode[l]; if (m.qkv != ZK_F16 || m.att != ZK_F16 || m.o != ZK_F16 || m.mlp != ZK_F16) return true; }
+    return base_mode() != ZK_F16;
+  }
+  void set_mode(int m) {
+    mode = m;
+    for (int l = 0; l < ZK_LAYERS; ++l) {
+      if (m != ZK_F16MIX) { layer_mode[l] = LayerMode{m, m, m, m}; continue; }
+      const int g = (ZK_MIX_X3_MASK >> (4 * l)) & 15;      // bit 0 QKV, 1 QK^T, 2 O, 3 MLP
+      layer_mode[l] = LayerMode{g & 1 ? ZK_F16X3 : ZK_F16C8, g & 2 ? ZK_F16X3 : ZK_F16C8, g & 4 ? ZK_F16X3 : ZK_F16C8, g & 8 ? ZK_F16X3 : ZK_F16C8};
+    }
+  }
   int num_labels = 2;
   int n_layers = ZK_LAYERS;
   float eps = 1e-12f;
@@ -95,7 +130,7 @@ struct StageModel {
   // for the rows that do not depend on the window, given (n_frames, compute mode, fx mean / std) — l0_frames < 0: not built
   float* l0_hidden = nullptr;
   half_t *l0_qkv_hi = nullptr, *l0_qkv_lo = nullptr;
-  int l0_frames = -1, l0_mode = 0;
+  int l0_frames = -1, l0_mode = 0, l0_base = 0;
   float l0_mean = 0.f, l0_std = 0.f;
   void release() {
     for (void* p : allocs) (void)hipFree(p);
@@ -106,9 +141,15 @@ struct StageModel {
 };
 
 enum ProfClass { P_GEMM_QKV, P_GEMM_O, P_GEMM_FC1, P_GEMM_FC2, P_GEMM_PATCH, P_ATTN, P_LN, P_LOGMEL, P_EMBED, P_HEAD, P_WAVDEC,
-                 P_RESAMPLE, P_N };
+                 P_RESAMPLE, P_ALLGATHER,
+                 // ZK_F16MIX only: the launches of the layers that run ZK_F16X3 are other kernels than the ZK_F16C8 ones and
+                 // are timed apart, so that each class stays ONE kernel instantiation (bench.py's roofline)
+                 P_GEMM_QKV_X3, P_GEMM_O_X3, P_GEMM_FC1_X3, P_GEMM_FC2_X3, P_ATTN_X3, P_N };
 const char* kProfNames[P_N] = {"gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch",
-                               "attention", "layernorm", "logmel", "embed", "head", "wav_decode", "resample"};
+                               "attention", "layernorm", "logmel", "embed", "head", "wav_decode", "resample", "allgather",
+                               "gemm_qkv_x3", "gemm_o_x3", "gemm_fc1_x3", "gemm_fc2_x3", "attention_x3"};
+// class of a layer kernel: inside a ZK_F16MIX model the ZK_F16X3 layers count apart
+
 
 }  // namespace
 
@@ -449,17 +490,12 @@ inline int patch_lo_fmt(int ns) { return patch_mode(ns) == ZK_F16C8 ? ZK_LO_C8 :
 // residual stream and of the layer-0 q|k|v planes come from the model's table (build_l0_table), LayerNorm 1 and the QKV GEMM
 // of layer 0 run on the 12·tr real rows of every window (1.5 % of a forward's FLOPs less; results bit-identical)
 int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0) {
-  const int ns = sm.mode;
-  const bool sp = ns != ZK_F16;
-  // lo-plane format of every GEMM operand: c8 byte pairs in ZK_F16C8 (of the QKV planes only k's columns: attention.hip)
-  const int lf = (ns == ZK_F16C8) ? ZK_LO_C8 : ZK_LO_F16;
   const int M = nb * ZK_SEQ;
   float* hidden = c->hidden.as<float>();
-  zk_planes pa = c->patchA.get(sp, patch_lo_fmt(ns)), xn = c->xn.get(sp, lf), qkv = c->qkv.get(sp), att = c->att.get(sp, lf),
-            mid = c->mid.get(sp, lf);
-  // ZK_F16C8: the big GEMM operands that a GEMM-side kernel both writes and reads go as k-slice-major tiles
-  // (zk_planes::tiled; the workspace planes hold whole 256-row blocks): LayerNorm -> QKV / FC1, FC1 -> FC2, attention -> O
-  if (ns == ZK_F16C8) { xn.tiled = ZK_XN_TILED; mid.tiled = ZK_MID_TILED; att.tiled = ZK_ATT_TILED; }
+  {
+    const int ns = sm.base_mode();
+    const bool sp = ns != ZK_F16;
+    zk_planes pa = c->patchA.get(sp, patch_lo_fmt(ns));
   {
     ProfScope ps(c, P_EMBED);
     if (tr) zk_launch_l0_fill_hidden(hidden, sm.l0_hidden, nb, tr, c->stream);
@@ -467,6 +503,7 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0
   }
   if (int grc = run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w, sm.patch_b, nb * (tr ? ZK_FOUT * tr : ZK_NPATCH), ZK_HIDDEN, ZK_PATCH_K,
            ZK_EPI_PATCH, patch_mode(ns), zk_planes{nullptr, nullptr, 0}, hidden, sm.pos, 0, 1 << 30, 0, 1 << 30, tr)) return grc;
+  }
   if (c->tap_layer == -1) {
     HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
     HIPCHK(c, hipMemcpyAsync(c->tap.p, hidden, (size_t)M * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -476,6 +513,29 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0
   c->walk_dir = 1;      // the patch GEMM above walked forwards: the first LayerNorm starts from the end
   for (int l = 0; l < sm.n_layers; ++l) {
     const LayerW& L = sm.L[l];
+    // the layer's compute mode (ZK_F16MIX: per layer; otherwise the model's): the planes between its kernels follow it, the
+    // fp32 residual stream is all that crosses a layer boundary
+    const LayerMode lm = sm.layer_mode[l];
+    // An operand's planes follow the GEMM that READS them: lo-plane format c8 byte pairs for a ZK_F16C8 consumer, else fp16
+    // (of the QKV planes only k's columns are ever c8, for attention's fp8-corrected QK^T), and for a ZK_F16C8 consumer the
+    // big operands that a GEMM-side kernel both writes and reads go as k-slice-major tiles (zk_planes::tiled; the
+    // workspace planes hold whole 256-row blocks): LayerNorm -> QKV / FC1, FC1 -> FC2, attention -> O
+    auto lof = [](int m) { return m == ZK_F16C8 ? ZK_LO_C8 : ZK_LO_F16; };
+    const int ns_q = lm.qkv, ns_o = lm.o, ns_m = lm.mlp;
+    const bool sp_q = ns_q != ZK_F16, sp_o = ns_o != ZK_F16, sp_m = ns_m != ZK_F16;
+    zk_planes xn = c->xn.get(sp_q, lof(ns_q)), qkv = c->qkv.get(sp_q), att = c->att.get(sp_o, lof(ns_o)),
+              xn2 = c->xn.get(sp_m, lof(ns_m)), mid = c->mid.get(sp_m, lof(ns_m));
+    if (ns_q == ZK_F16C8) xn.tiled = ZK_XN_TILED;
+    if (ns_o == ZK_F16C8) att.tiled = ZK_ATT_TILED;
+    if (ns_m == ZK_F16C8) { xn2.tiled = ZK_XN_TILED; mid.tiled = ZK_MID_TILED; }
+    // k's lo plane: c8 byte pairs exactly when attention runs the fp8-corrected QK^T
+    const bool k_c8 = lm.att == ZK_F16C8;
+    const int att_split = lm.att == ZK_F16C8 ? 2 : (lm.att == ZK_F16X3 ? 3 : 1);
+    // profile classes of this layer's kernels (the ZK_F16X3 launches of a ZK_F16MIX model are timed apart)
+    const bool mix = sm.mode == ZK_F16MIX;
+    const int P_QKV = (mix && ns_q == ZK_F16X3) ? P_GEMM_QKV_X3 : P_GEMM_QKV, P_O = (mix && ns_o == ZK_F16X3) ? P_GEMM_O_X3 : P_GEMM_O,
+              P_FC1 = (mix && ns_m == ZK_F16X3) ? P_GEMM_FC1_X3 : P_GEMM_FC1, P_FC2 = (mix && ns_m == ZK_F16X3) ? P_GEMM_FC2_X3 : P_GEMM_FC2,
+              P_AT = (mix && lm.att == ZK_F16X3) ? P_ATTN_X3 : P_ATTN;
     // Only tokens 0/1 reach the head (ASTModel.forward:304), so in the LAST layer the queries, the attention output
     // projection and the MLP are needed for those two rows only (exact: same arithmetic per row).  K/V still need every
     // token.  Disabled while a debug tap wants the full residual stream of that layer.
@@ -486,7 +546,7 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0
     const bool l0 = tr > 0 && l == 0;
     const int Mq = l0 ? nb * ZK_FOUT * tr : M;
     zk_planes qkv_dst = qkv;
-    if (l0) { qkv_dst = c->mid.get(sp); qkv_dst.lo_fmt = qkv.lo_fmt; }
+    if (l0) { qkv_dst = c->mid.get(sp_q); qkv_dst.lo_fmt = qkv.lo_fmt; }
     { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, Mq, xn, sm.eps, c->stream, next_dir(c), l0 ? tr : 0); }
     // lo planes of the fused QKV: q fp16 (re-split by attention), k c8 byte pairs in ZK_F16C8 (fp8-corrected QK^T) else
     // fp16, v fp16 (attention's Vl·P pass)
@@ -502,51 +562,51 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0
       wkv.hi += (size_t)ZK_HIDDEN * ZK_HIDDEN; wkv.lo += (size_t)ZK_HIDDEN * ZK_HIDDEN; wkv.c8 += (size_t)ZK_HIDDEN * ZK_HIDDEN;
       zk_planes kv = qkv;
       kv.hi += ZK_HIDDEN; if (kv.lo) kv.lo += ZK_HIDDEN;
-      if (int grc = run_gemm(c, P_GEMM_QKV, xn, wkv, L.bqkv + ZK_HIDDEN, M, 2 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, kv,
-               nullptr, nullptr, 2 * ZK_HIDDEN, ns == ZK_F16C8 ? 0 : 1 << 30, next_dir(c), ZK_HIDDEN, 0, 3 * ZK_HIDDEN)) return grc;
-      zk_planes xq = c->mid.get(sp, lf), q32 = c->att.get(sp);
-      xq.rowexp = (sp && lf == ZK_LO_C8) ? c->xq_rowexp.as<int32_t>() : nullptr;
+      if (int grc = run_gemm(c, P_QKV, xn, wkv, L.bqkv + ZK_HIDDEN, M, 2 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns_q, kv,
+               nullptr, nullptr, 2 * ZK_HIDDEN, k_c8 ? 0 : 1 << 30, next_dir(c), ZK_HIDDEN, 0, 3 * ZK_HIDDEN)) return grc;
+      zk_planes xq = c->mid.get(sp_q, lof(ns_q)), q32 = c->att.get(sp_q);
+      xq.rowexp = (sp_q && ns_q == ZK_F16C8) ? c->xq_rowexp.as<int32_t>() : nullptr;
       { ProfScope ps(c, P_EMBED); zk_launch_gather_xq(xn, nb, xq, c->stream); }
-      if (int grc = run_gemm(c, P_GEMM_QKV, xq, L.wqkv, L.bqkv, ZK_QROWS * nb, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, q32,
+      if (int grc = run_gemm(c, P_QKV, xq, L.wqkv, L.bqkv, ZK_QROWS * nb, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns_q, q32,
                nullptr, nullptr, ZK_HIDDEN)) return grc;
       { ProfScope ps(c, P_EMBED); zk_launch_scatter_q(q32, nb, qkv, c->stream); }
     } else
-    if (int grc = run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, Mq, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv_dst,
-             nullptr, nullptr, 3 * ZK_HIDDEN, ns == ZK_F16C8 ? ZK_HIDDEN : 1 << 30, next_dir(c), 2 * ZK_HIDDEN)) return grc;
+    if (int grc = run_gemm(c, P_QKV, xn, L.wqkv, L.bqkv, Mq, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns_q, qkv_dst,
+             nullptr, nullptr, 3 * ZK_HIDDEN, k_c8 ? ZK_HIDDEN : 1 << 30, next_dir(c), 2 * ZK_HIDDEN)) return grc;
     if (l0) {
       ProfScope ps(c, P_EMBED);
-      zk_planes tab{sm.l0_qkv_hi, sp ? sm.l0_qkv_lo : nullptr, qkv.lo_fmt};
+      zk_planes tab{sm.l0_qkv_hi, sp_q ? sm.l0_qkv_lo : nullptr, qkv.lo_fmt};
       zk_launch_l0_assemble_qkv(qkv_dst, tab, qkv, nb, tr, c->stream);
     }
     {
-      ProfScope ps(c, P_ATTN);
+      ProfScope ps(c, P_AT);
       // pruned last layer: only the query rows whose q exists are worth computing — one wave's 32 with ZK_PRUNE_Q (the
       // other waves of the workgroup still help staging K / V), else the first 128-row block
       const bool q32 = last && l > 0 && ZK_PRUNE_Q == 1;
       const int qt = last ? (q32 ? -ZK_QROWS : 1) : 10;
-      if (c->prof) c->prof_flops[P_ATTN] += (double)nb * ZK_HEADS * 4.0 * (last ? (q32 ? (double)ZK_QROWS : 128.0) : (double)ZK_SEQ) * ZK_SEQ * ZK_HEAD_DIM;
-      zk_launch_attention(qkv, att, nb, ns == ZK_F16C8 ? 2 : (sp ? 3 : 1), qt, c->stream, next_dir(c));
+      if (c->prof) c->prof_flops[P_AT] += (double)nb * ZK_HEADS * 4.0 * (last ? (q32 ? (double)ZK_QROWS : 128.0) : (double)ZK_SEQ) * ZK_SEQ * ZK_HEAD_DIM;
+      zk_launch_attention(qkv, att, nb, att_split, qt, c->stream, next_dir(c));
     }
     if (last) {
-      zk_planes att_s = c->att_s.get(sp, lf), xn_s = c->xn_s.get(sp, lf), mid_s = c->mid_s.get(sp, lf);
+      zk_planes att_s = c->att_s.get(sp_o, lof(ns_o)), xn_s = c->xn_s.get(sp_m, lof(ns_m)), mid_s = c->mid_s.get(sp_m, lof(ns_m));
       float* hs = c->hidden_s.as<float>();
       { ProfScope ps(c, P_EMBED); zk_launch_gather_tok01(att, hidden, nb, att_s, hs, c->stream); }
-      if (int grc = run_gemm(c, P_GEMM_O, att_s, L.wo, L.bo, 2 * nb, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
+      if (int grc = run_gemm(c, P_O, att_s, L.wo, L.bo, 2 * nb, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns_o,
                zk_planes{nullptr, nullptr, 0}, hs, nullptr, 0)) return grc;
       { ProfScope ps(c, P_LN); zk_launch_layernorm(hs, ZK_HIDDEN, L.ln2_g, L.ln2_b, 2 * nb, xn_s, sm.eps, c->stream); }
-      if (int grc = run_gemm(c, P_GEMM_FC1, xn_s, L.w1, L.b1, 2 * nb, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid_s, nullptr,
+      if (int grc = run_gemm(c, P_FC1, xn_s, L.w1, L.b1, 2 * nb, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns_m, mid_s, nullptr,
                nullptr, ZK_INTER)) return grc;
-      if (int grc = run_gemm(c, P_GEMM_FC2, mid_s, L.w2, L.b2, 2 * nb, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
+      if (int grc = run_gemm(c, P_FC2, mid_s, L.w2, L.b2, 2 * nb, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns_m,
                zk_planes{nullptr, nullptr, 0}, hs, nullptr, 0)) return grc;
       pruned = true;
       continue;
     }
-    if (int grc = run_gemm(c, P_GEMM_O, att, L.wo, L.bo, M, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns,
+    if (int grc = run_gemm(c, P_O, att, L.wo, L.bo, M, ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_RESID, ns_o,
              zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c))) return grc;
-    { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln2_g, L.ln2_b, M, xn, sm.eps, c->stream, next_dir(c)); }
-    if (int grc = run_gemm(c, P_GEMM_FC1, xn, L.w1, L.b1, M, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns, mid, nullptr, nullptr,
+    { ProfScope ps(c, P_LN); zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln2_g, L.ln2_b, M, xn2, sm.eps, c->stream, next_dir(c)); }
+    if (int grc = run_gemm(c, P_FC1, xn2, L.w1, L.b1, M, ZK_INTER, ZK_HIDDEN, ZK_EPI_GELU, ns_m, mid, nullptr, nullptr,
              ZK_INTER, 1 << 30, next_dir(c))) return grc;
-    if (int grc = run_gemm(c, P_GEMM_FC2, mid, L.w2, L.b2, M, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns,
+    if (int grc = run_gemm(c, P_FC2, mid, L.w2, L.b2, M, ZK_HIDDEN, ZK_INTER, ZK_EPI_RESID, ns_m,
              zk_planes{nullptr, nullptr, 0}, hidden, nullptr, 0, 1 << 30, next_dir(c))) return grc;
     if (c->tap_layer == l) {
       HIPCHK(c, c->tap.ensure((size_t)M * ZK_HIDDEN * 4));
@@ -571,31 +631,40 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0
 // launch: the micro-batch invariance tests pin that), and copied from then on.  Depends on the weights, the compute
 // mode, the extractor's mean / std (the pad value) and n_frames.
 int build_l0_table(zk_ctx* c, StageModel& sm, int n_frames) {
-  const int ns = sm.mode;
-  const bool sp = ns != ZK_F16;
+  const int ns = sm.layer_mode[0].qkv, nsb = sm.base_mode();
+  const bool k_c8 = sm.layer_mode[0].att == ZK_F16C8;      // k's lo plane as c8 byte pairs (attention's fp8-corrected QK^T)
+  const bool sp = ns != ZK_F16, spb = nsb != ZK_F16;
   const int lf = (ns == ZK_F16C8) ? ZK_LO_C8 : ZK_LO_F16;
-  int rc = ensure_workspace(c, 1, sp);
+  sm.l0_frames = -1;      // until the table below is complete the forward takes the ordinary path
+  int rc = ensure_workspace(c, 1, sp || spb);
   if (rc) return rc;
-  if (!sm.l0_hidden) {
-    HIPCHK(c, hipMalloc((void**)&sm.l0_hidden, (size_t)ZK_SEQ * ZK_HIDDEN * 4)); sm.allocs.push_back(sm.l0_hidden);
-    HIPCHK(c, hipMalloc((void**)&sm.l0_qkv_hi, (size_t)ZK_SEQ * 3 * ZK_HIDDEN * 2)); sm.allocs.push_back(sm.l0_qkv_hi);
-    HIPCHK(c, hipMalloc((void**)&sm.l0_qkv_lo, (size_t)ZK_SEQ * 3 * ZK_HIDDEN * 2)); sm.allocs.push_back(sm.l0_qkv_lo);
+  if (!sm.l0_hidden || !sm.l0_qkv_hi || !sm.l0_qkv_lo) {      // all three or none: a failed hipMalloc leaves the model without a table
+    void* t[3] = {nullptr, nullptr, nullptr};
+    const size_t bytes[3] = {(size_t)ZK_SEQ * ZK_HIDDEN * 4, (size_t)ZK_SEQ * 3 * ZK_HIDDEN * 2, (size_t)ZK_SEQ * 3 * ZK_HIDDEN * 2};
+    for (int i = 0; i < 3; ++i)
+      if (hipMalloc(&t[i], bytes[i]) != hipSuccess) {
+        (void)hipGetLastError();
+        for (int j = 0; j < i; ++j) (void)hipFree(t[j]);
+        return fail(c, ZK_E_NOMEM, "layer-0 constant-row table: out of device memory");
+      }
+    sm.l0_hidden = (float*)t[0]; sm.l0_qkv_hi = (half_t*)t[1]; sm.l0_qkv_lo = (half_t*)t[2];
+    for (void* p : t) sm.allocs.push_back(p);
   }
   const bool was_prof = c->prof;
   c->prof = false;      // a one-off: keep it out of the per-class timings of a profiled region
   float* hidden = c->hidden.as<float>();
-  zk_planes pa = c->patchA.get(sp, patch_lo_fmt(ns)), xn = c->xn.get(sp, lf), qkv = c->qkv.get(sp);
+  zk_planes pa = c->patchA.get(spb, patch_lo_fmt(nsb)), xn = c->xn.get(sp, lf), qkv = c->qkv.get(sp);
   if (ns == ZK_F16C8) xn.tiled = ZK_XN_TILED;
   const LayerW& L = sm.L[0];
   // window 0 of the feature slot: which window it is does not matter for the rows that are kept
   zk_launch_im2col_compact(c->feat.as<float>(), n_frames, nullptr, 1, sm.mean, sm.std * 2.0f, pa, c->stream);
   zk_launch_cls_rows(hidden, sm.cls, sm.dist, sm.pos, 1, c->stream);
-  rc = run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w, sm.patch_b, ZK_NPATCH, ZK_HIDDEN, ZK_PATCH_K, ZK_EPI_PATCH, patch_mode(ns),
+  rc = run_gemm(c, P_GEMM_PATCH, pa, sm.patch_w, sm.patch_b, ZK_NPATCH, ZK_HIDDEN, ZK_PATCH_K, ZK_EPI_PATCH, patch_mode(nsb),
                 zk_planes{nullptr, nullptr, 0}, hidden, sm.pos, 0);
   if (!rc) {
     zk_launch_layernorm(hidden, ZK_HIDDEN, L.ln1_g, L.ln1_b, ZK_SEQ, xn, sm.eps, c->stream);
     rc = run_gemm(c, P_GEMM_QKV, xn, L.wqkv, L.bqkv, ZK_SEQ, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns, qkv, nullptr, nullptr,
-                  3 * ZK_HIDDEN, ns == ZK_F16C8 ? ZK_HIDDEN : 1 << 30, 0, 2 * ZK_HIDDEN);
+                  3 * ZK_HIDDEN, k_c8 ? ZK_HIDDEN : 1 << 30, 0, 2 * ZK_HIDDEN);
   }
   c->prof = was_prof;
   if (rc) return rc;
@@ -603,14 +672,18 @@ int build_l0_table(zk_ctx* c, StageModel& sm, int n_frames) {
   HIPCHK(c, hipMemcpyAsync(sm.l0_hidden, hidden, (size_t)ZK_SEQ * ZK_HIDDEN * 4, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(sm.l0_qkv_hi, qkv.hi, (size_t)ZK_SEQ * 3 * ZK_HIDDEN * 2, hipMemcpyDeviceToDevice, c->stream));
   if (sp) HIPCHK(c, hipMemcpyAsync(sm.l0_qkv_lo, qkv.lo, (size_t)ZK_SEQ * 3 * ZK_HIDDEN * 2, hipMemcpyDeviceToDevice, c->stream));
-  sm.l0_frames = n_frames; sm.l0_mode = ns; sm.l0_mean = sm.mean; sm.l0_std = sm.std;
+  // a one-off per model: wait for the copies, so that the table is complete whatever stream a later forward runs on
+  // (zk_set_stream, async mode)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  sm.l0_frames = n_frames; sm.l0_mode = ns * 2 + (k_c8 ? 1 : 0); sm.l0_base = nsb; sm.l0_mean = sm.mean; sm.l0_std = sm.std;
   return ZK_OK;
 }
 
 // src_full != nullptr: device (B,1024,128) normalised; else feature slot with optional device index list
 int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d_idx, int B, float* d_logits) {
   StageModel& sm = c->model[stage];
-  const bool sp = sm.mode != ZK_F16;
+  const bool sp = sm.any_split();
+  const bool spb = sm.base_mode() != ZK_F16;      // the patch matrix follows the model's base mode
   // micro_batch == 0 (auto).  Large batches: as few, equal micro-batches of at most 512 windows as possible (≈ 21 GB of
   // activations; every GEMM then runs >= 12 rounds of the 256 persistent workgroups and the per-launch tails and
   // the ragged last micro-batch stop mattering: 1024 windows as 2 x 512 measured +3 % over 9 x 107 + 61).  Small
@@ -637,8 +710,12 @@ int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d
     tr = (c->feat_frames + ZK_TSTRIDE - 1) / ZK_TSTRIDE;
     if (tr >= ZK_TOUT) tr = 0;
   }
-  if (tr && (sm.l0_frames != c->feat_frames || sm.l0_mode != sm.mode || sm.l0_mean != sm.mean || sm.l0_std != sm.std))
-    if ((rc = build_l0_table(c, sm, c->feat_frames))) return rc;
+  if (tr && (sm.l0_frames != c->feat_frames || sm.l0_mode != sm.layer_mode[0].qkv * 2 + (sm.layer_mode[0].att == ZK_F16C8 ? 1 : 0) ||
+             sm.l0_base != sm.base_mode() ||
+             sm.l0_mean != sm.mean || sm.l0_std != sm.std)) {
+    // a table that cannot be built (out of memory) only costs the shortcut: the forward takes the ordinary path
+    if (build_l0_table(c, sm, c->feat_frames) != ZK_OK) tr = 0;
+  }
   bool tapped = false;
   const int saved_tap = c->tap_layer;
   for (int b0 = 0; b0 < B; b0 += mbs) {
@@ -646,11 +723,11 @@ int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d
     {
       ProfScope ps(c, P_EMBED);
       if (src_full)
-        zk_launch_im2col_full(src_full + (size_t)b0 * ZK_MAXLEN * ZK_NMEL, nb, c->patchA.get(sp, patch_lo_fmt(sm.mode)), c->stream);
+        zk_launch_im2col_full(src_full + (size_t)b0 * ZK_MAXLEN * ZK_NMEL, nb, c->patchA.get(spb, patch_lo_fmt(sm.base_mode())), c->stream);
       else
         zk_launch_im2col_compact(c->feat.as<float>() + (d_idx ? 0 : (size_t)b0 * c->feat_frames * ZK_NMEL),
                                  c->feat_frames, d_idx ? d_idx + b0 : nullptr, nb, sm.mean, sm.std * 2.0f,
-                                 c->patchA.get(sp, patch_lo_fmt(sm.mode)), c->stream, tr);
+                                 c->patchA.get(spb, patch_lo_fmt(sm.base_mode())), c->stream, tr);
     }
     if (tapped) c->tap_layer = -2;  // tap only the first micro-batch
     rc = forward_micro(c, sm, nb, d_logits + (size_t)b0 * sm.num_labels, tr);
@@ -697,6 +774,9 @@ hipStream_t zk_ctx_stream(zk_ctx* c) { return c->stream; }
 int zk_ctx_device(zk_ctx* c) { return c->device; }
 int zk_ctx_fail(zk_ctx* c, int code, const char* msg) { return fail(c, code, "%s", msg); }
 void** zk_ctx_comm_slot(zk_ctx* c) { return &c->comm; }
+// HIP-event bracket of the "allgather" profile class around what comm.hip queues on the context's stream
+void* zk_ctx_prof_open_allgather(zk_ctx* c) { return c->prof ? new ProfScope(c, P_ALLGATHER) : nullptr; }
+void zk_ctx_prof_close(void* scope) { delete (ProfScope*)scope; }
 void* zk_ctx_stage_buf(zk_ctx* c, int which, size_t bytes) {
   if (c->comm_stage[which & 1].ensure(bytes) != hipSuccess) { fail(c, ZK_E_NOMEM, "comm staging buffer of %zu bytes", bytes); return nullptr; }
   return c->comm_stage[which & 1].p;
@@ -705,7 +785,7 @@ void* zk_ctx_stage_buf(zk_ctx* c, int which, size_t bytes) {
 // =====================================================================================================================
 extern "C" {
 
-const char* zk_version(void) { return "zkast 0.4 (gfx950)"; }
+const char* zk_version(void) { return "zkast 0.5 (gfx950)"; }
 
 int zk_create(int device_id, zk_ctx** out) {
   if (!out) return fail(nullptr, ZK_E_ARG, "out is NULL");
@@ -787,8 +867,8 @@ int zk_model_load(zk_ctx* c, int stage, const zk_tensor_desc* t, int32_t n, cons
   if (!c) return ZK_E_ARG;
   if (stage < 0 || stage > 1) return fail(c, ZK_E_ARG, "stage must be 0 or 1");
   if (!t || n <= 0 || !cfg) return fail(c, ZK_E_ARG, "tensors/cfg missing");
-  if (mode != ZK_F16 && mode != ZK_F16X3 && mode != ZK_F16C8)
-    return fail(c, ZK_E_ARG, "compute_mode must be ZK_F16 (1), ZK_F16C8 (2) or ZK_F16X3 (3)");
+  if (mode != ZK_F16 && mode != ZK_F16X3 && mode != ZK_F16C8 && mode != ZK_F16MIX)
+    return fail(c, ZK_E_ARG, "compute_mode must be ZK_F16 (1), ZK_F16C8 (2), ZK_F16X3 (3) or ZK_F16MIX (4)");
   if (cfg->hidden_size != ZK_HIDDEN || cfg->num_attention_heads != ZK_HEADS || cfg->intermediate_size != ZK_INTER ||
       cfg->patch_size != ZK_PATCH || cfg->frequency_stride != ZK_FSTRIDE || cfg->time_stride != ZK_TSTRIDE ||
       cfg->max_length != ZK_MAXLEN || cfg->num_mel_bins != ZK_NMEL)
@@ -800,7 +880,7 @@ int zk_model_load(zk_ctx* c, int stage, const zk_tensor_desc* t, int32_t n, cons
   HIPCHK(c, hipSetDevice(c->device));
   StageModel& sm = c->model[stage];
   sm.release();
-  sm.mode = mode; sm.num_labels = cfg->num_labels; sm.n_layers = cfg->num_hidden_layers; sm.eps = cfg->layer_norm_eps;
+  sm.set_mode(mode); sm.num_labels = cfg->num_labels; sm.n_layers = cfg->num_hidden_layers; sm.eps = cfg->layer_norm_eps;
   sm.mean = fx_mean; sm.std = fx_std;
 
   TensorIndex ix;
@@ -864,8 +944,29 @@ int zk_model_load(zk_ctx* c, int stage, const zk_tensor_desc* t, int32_t n, cons
 int zk_model_set_compute_mode(zk_ctx* c, int stage, int32_t mode) {
   int rc = check_stage(c, stage);
   if (rc) return rc;
-  if (mode != ZK_F16 && mode != ZK_F16X3 && mode != ZK_F16C8) return fail(c, ZK_E_ARG, "compute_mode must be 1, 2 or 3");
-  c->model[stage].mode = mode;
+  if (mode != ZK_F16 && mode != ZK_F16X3 && mode != ZK_F16C8 && mode != ZK_F16MIX) return fail(c, ZK_E_ARG, "compute_mode must be 1, 2, 3 or 4");
+  c->model[stage].set_mode(mode);
+  return ZK_OK;
+}
+
+int zk_model_set_layer_modes(zk_ctx* c, int stage, const int32_t* modes, int32_t n) {
+  int rc = check_stage(c, stage);
+  if (rc) return rc;
+  StageModel& sm = c->model[stage];
+  if (!modes || (n != sm.n_layers && n != 4 * sm.n_layers))
+    return fail(c, ZK_E_ARG, "zk_model_set_layer_modes: need %d modes (one per encoder layer) or %d (QKV, QK^T, O, MLP of each layer), got %d",
+                sm.n_layers, 4 * sm.n_layers, n);
+  const bool per_kind = n == 4 * sm.n_layers;
+  LayerMode lm[ZK_LAYERS];
+  for (int l = 0; l < sm.n_layers; ++l) {
+    lm[l] = per_kind ? LayerMode{modes[4 * l], modes[4 * l + 1], modes[4 * l + 2], modes[4 * l + 3]} : LayerMode{modes[l], modes[l], modes[l], modes[l]};
+    if (!layer_mode_ok(lm[l]))
+      return fail(c, ZK_E_ARG, "zk_model_set_layer_modes: layer %d: modes (%d, %d, %d, %d) — each must be ZK_F16 / ZK_F16C8 / ZK_F16X3, "
+                  "ZK_F16C8 for QK^T needs the ZK_F16C8 QKV GEMM (it writes k's c8 plane), a split QK^T a split QKV GEMM",
+                  l, lm[l].qkv, lm[l].att, lm[l].o, lm[l].mlp);
+  }
+  sm.mode = ZK_F16MIX;
+  for (int l = 0; l < sm.n_layers; ++l) sm.layer_mode[l] = lm[l];
   return ZK_OK;
 }
 

@@ -14,20 +14,35 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ZKAST_LIB: alternative build of the same library (kernel experiments under tools/); default is the in-tree build
+# ZKAST_LIB: alternative build of the same library (kernel experiments under tools/); default is the in-tree build.
+# The library is linked -no-hip-rt (no DT_NEEDED on libamdhip64): open it through load_library(), or after a HIP runtime is
+# in the global scope (_ensure_hip_runtime) — a bare dlopen in a process without one fails on unresolved hip* symbols.
 LIB_PATH = os.environ.get("ZKAST_LIB") or os.path.join(_HERE, "libzkast.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
-ZK_F16, ZK_F16C8, ZK_F16X3 = 1, 2, 3
+ZK_F16, ZK_F16C8, ZK_F16X3, ZK_F16MIX = 1, 2, 3, 4
 ZK_DT_F32, ZK_DT_F16, ZK_DT_BF16 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_PATCH = 0, 1, 2, 3
 TEST_TILED_IN, TEST_TILED_OUT, TEST_POISON_PAD, TEST_SHORT_X = 0x100, 0x200, 0x400, 0x800      # include/zkast.h: ZK_TEST_*
-COMPUTE_MODES = {"f16": ZK_F16, "f16c8": ZK_F16C8, "f16x3": ZK_F16X3, 1: ZK_F16, 2: ZK_F16C8, 3: ZK_F16X3}
+# the kernel groups ZK_F16MIX runs as ZK_F16X3 (everything else ZK_F16C8), {layer: groups}: ZK_MIX_X3_MASK of csrc/zkast.hip
+LAYER_GROUPS = ("qkv", "att", "o", "mlp")      # fused QKV GEMM, QK^T of attention, O projection, MLP (FC1 + FC2)
+MIX_X3_GROUPS = {0: ("qkv", "att", "o", "mlp")}
+
+
+def mix_layer_modes(x3_groups=None, n_layers: int = 12) -> list:
+    """per-layer (qkv, att, o, mlp) mode tuples of a ZK_F16MIX assignment: f16x3 for the groups named in `x3_groups`
+    ({layer: groups}, default MIX_X3_GROUPS), f16c8 elsewhere"""
+    g = MIX_X3_GROUPS if x3_groups is None else x3_groups
+    return [tuple("f16x3" if k in g.get(l, ()) else "f16c8" for k in LAYER_GROUPS) for l in range(n_layers)]
+# what the drop-in classes, the CLIs and bench.py use unless told otherwise: the cheapest mode that keeps >= 20 % of the 1e-3
+# logit tolerance on a configs[3]-sized recording of the input-sensitive weight set (tests/test_sens_tail_gpu.py)
+DEFAULT_COMPUTE_MODE = "f16c8"
+COMPUTE_MODES = {"f16": ZK_F16, "f16c8": ZK_F16C8, "f16x3": ZK_F16X3, "f16mix": ZK_F16MIX, 1: ZK_F16, 2: ZK_F16C8, 3: ZK_F16X3, 4: ZK_F16MIX}
 
 # every symbol include/zkast.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
     "zk_create", "zk_destroy", "zk_last_error", "zk_set_stream", "zk_set_async", "zk_synchronize",
-    "zk_set_micro_batch", "zk_set_prune_last_layer", "zk_set_layer0_reuse", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_fx",
+    "zk_set_micro_batch", "zk_set_prune_last_layer", "zk_set_layer0_reuse", "zk_version", "zk_model_load", "zk_model_set_compute_mode", "zk_model_set_layer_modes", "zk_model_set_fx",
     "zk_logmel", "zk_features_expand", "zk_features_get", "zk_features_set", "zk_ast_forward", "zk_softmax", "zk_two_stage", "zk_gate",
     "zk_comm_unique_id", "zk_comm_init", "zk_comm_destroy", "zk_comm_info", "zk_allgather_logits", "zk_comm_allgather_bytes",
     "zk_resample", "zk_wav_decode", "zk_audio_load", "zk_audio_get", "zk_prof_begin", "zk_prof_end", "zk_prof_get", "zk_prof_get_flops", "zk_debug_set_tap", "zk_debug_get_tap",
@@ -84,10 +99,15 @@ def _ensure_hip_runtime() -> str:
     hip* symbols resolve against whichever runtime is in the global scope when it is loaded, and this function puts one
     there, in this order:
 
+      0. ``$ZKAST_HIP_LIB`` when set: the explicit override wins.  If ANOTHER libamdhip64 is already mapped the call raises
+         instead of loading a second runtime beside it;
       1. a libamdhip64 that is already mapped — the host imported torch first, or is a HIP application itself;
       2. the one a PyTorch wheel ships (``torch/lib/libamdhip64.so``, located WITHOUT importing torch): a later
          ``import torch`` then finds its runtime already loaded and shares it;
-      3. the system ROCm (``$ZKAST_HIP_LIB``, ``libamdhip64.so.7`` on the loader path, ``/opt/rocm/lib``).
+      3. the system ROCm (``libamdhip64.so.7`` on the loader path, ``/opt/rocm/lib``).
+
+    A loader that bypasses this function (a C host, another binding) must put a HIP runtime into the global scope itself
+    before it opens libzkast.so: the library is linked ``-no-hip-rt`` and has no DT_NEEDED that would do it.
 
     Why: a PyTorch-ROCm wheel carries its own SONAME-less ``libamdhip64.so`` + ``libhsa-runtime64.so``; with libzkast.so
     hard-wired to /opt/rocm's the process held two HIP and two HSA runtimes, and the one that came up second could not
@@ -96,6 +116,17 @@ def _ensure_hip_runtime() -> str:
     mode = getattr(os, "RTLD_GLOBAL", 0x100) | getattr(os, "RTLD_NOW", 0x2)
     tried = []
     cands = _mapped_libraries("libamdhip64.so")
+    override = os.environ.get("ZKAST_HIP_LIB")
+    if override:
+        other = [p for p in cands if os.path.realpath(p) != os.path.realpath(override)]
+        if other:
+            raise ZkError(f"ZKAST_HIP_LIB={override} but another HIP runtime is already mapped into this process ({other[0]}): "
+                          "two HIP runtimes cannot share a GPU; unset ZKAST_HIP_LIB or load libzkast before that runtime")
+        try:
+            C.CDLL(override, mode=mode)
+            return override
+        except OSError as e:
+            raise ZkError(f"ZKAST_HIP_LIB={override} could not be loaded: {e}") from e
     if not cands:
         try:
             import importlib.util
@@ -106,8 +137,7 @@ def _ensure_hip_runtime() -> str:
                     cands.append(p)
         except (ImportError, ValueError):
             pass
-    cands += [p for p in (os.environ.get("ZKAST_HIP_LIB"), "libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so.7",
-                          "libamdhip64.so") if p]
+    cands += ["libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so.7", "libamdhip64.so"]
     for path in cands:
         try:
             C.CDLL(path, mode=mode)      # an already-mapped file is not loaded again, only promoted to the global scope
@@ -142,6 +172,7 @@ def load_library() -> C.CDLL:
             "zk_version": (C.c_char_p, []),
             "zk_model_load": (C.c_int, [vp, C.c_int, C.POINTER(TensorDesc), i32, C.POINTER(ASTConfigC), f32, f32, i32]),
             "zk_model_set_compute_mode": (C.c_int, [vp, C.c_int, i32]),
+            "zk_model_set_layer_modes": (C.c_int, [vp, C.c_int, C.POINTER(i32), i32]),
             "zk_model_set_fx": (C.c_int, [vp, C.c_int, f32, f32]),
             "zk_logmel": (C.c_int, [vp, vp, i64, i64, i64, i32, i32]),
             "zk_features_expand": (C.c_int, [vp, f32, f32, i32, vp]),
@@ -185,7 +216,8 @@ def comm_unique_id() -> bytes:
     buf = C.create_string_buffer(128)
     rc = load_library().zk_comm_unique_id(buf)
     if rc:
-        raise ZkError(f"zk_comm_unique_id failed ({rc}): RCCL (librccl.so.1) could not be loaded")
+        why = load_library().zk_last_error(None)
+        raise ZkError(f"zk_comm_unique_id failed ({rc}): {why.decode() if why else 'RCCL (librccl.so.1) could not be loaded'}")
     return buf.raw
 
 
@@ -206,7 +238,8 @@ def _ptr(x):
 
 
 PROF_CLASSES = ["gemm_qkv", "gemm_o", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention", "layernorm", "logmel",
-                "embed", "head", "wav_decode", "resample"]
+                "embed", "head", "wav_decode", "resample", "allgather",
+                "gemm_qkv_x3", "gemm_o_x3", "gemm_fc1_x3", "gemm_fc2_x3", "attention_x3"]
 
 
 class Context:
@@ -300,6 +333,21 @@ class Context:
 
     def set_compute_mode(self, stage: int, mode):
         self._chk(self.lib.zk_model_set_compute_mode(self.h, int(stage), COMPUTE_MODES[mode]), "zk_model_set_compute_mode")
+
+    def set_layer_modes(self, stage: int, modes):
+        """one compute mode per encoder layer ("f16c8" / "f16x3" / "f16"), or one (qkv, att, o, mlp) tuple of modes per
+        layer; the model's mode becomes f16mix"""
+        per_group = any(isinstance(m, (tuple, list)) for m in modes)
+        flat = []
+        for m in modes:
+            if isinstance(m, (tuple, list)):
+                if len(m) != 4:
+                    raise ValueError("a per-layer entry is one mode or a (qkv, att, o, mlp) tuple of modes")
+                flat += [COMPUTE_MODES[v] for v in m]
+            else:
+                flat += [COMPUTE_MODES[m]] * (4 if per_group else 1)
+        arr = (C.c_int32 * len(flat))(*flat)
+        self._chk(self.lib.zk_model_set_layer_modes(self.h, int(stage), arr, len(flat)), "zk_model_set_layer_modes")
 
     def set_fx(self, stage: int, mean: float, std: float):
         self._chk(self.lib.zk_model_set_fx(self.h, int(stage), float(mean), float(std)), "zk_model_set_fx")

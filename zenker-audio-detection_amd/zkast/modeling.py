@@ -135,6 +135,11 @@ class ZkASTForAudioClassification:
         self.compute_mode = mode
         self._ctx.set_compute_mode(self.stage, mode)
 
+    def set_layer_modes(self, modes):
+        """per-layer compute modes (ZK_F16MIX): e.g. ["f16x3"] * 4 + ["f16c8"] * 8"""
+        self.compute_mode = "f16mix"
+        self._ctx.set_layer_modes(self.stage, list(modes))
+
     def __call__(self, input_values=None, **kwargs):
         return self.forward(input_values, **kwargs)
 
