@@ -21,6 +21,8 @@ def main():
     names = sys.argv[2].split(",")
     M = windows * 1214
     shapes = [("qkv", 2304, 768, 0), ("fc1", 3072, 768, 1), ("o", 768, 768, 2), ("fc2", 768, 3072, 2)]
+    if os.environ.get("ZKP_SHAPES"):      # e.g. ZKP_SHAPES=fc1,qkv
+        shapes = [sh for sh in shapes if sh[0] in os.environ["ZKP_SHAPES"].split(",")]
     clocks = {}
     for n in names:
         lib = _hip_cdll(os.path.join(ZK, f"libzkast_probes_{n}.so"))

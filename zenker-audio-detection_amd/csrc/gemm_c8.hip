@@ -138,9 +138,25 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
 
   const int tiles_n = a.N / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
-  const int ntiles = tiles_m * tiles_n;
   const int nk = a.K / BK;
   const int per = gridDim.x >> 3;
+#ifndef ZK_C8_WALK
+#define ZK_C8_WALK 0
+#endif
+#if ZK_C8_WALK
+  // probe (round 5, VERDICT item 3: what W's re-fetch costs in clock): the 32 workgroups of an XCD form one SUPER TILE of
+  // WR row blocks x WC column tiles, and the super tiles are walked column-group-major, so all eight XCDs stay on the same WC
+  // column panels of W (WC x 786 KB for K = 768: L2-resident) for tiles_m / (8 WR) consecutive rounds; an X row block is
+  // shared by the WC workgroups of ONE XCD and read again once per column group.  Tile index t = 32 s + j of the linear
+  // walk (s = super tile, j = workgroup of the XCD) is all `phys` needs.  Row blocks past tiles_m (the last row group is
+  // partial) load the last real block and store nothing (m >= M).
+  constexpr int WC = ZK_C8_WALK, WR = 32 / WC;
+  const bool walk = (EPI == ZK_EPI_GELU || EPI == ZK_EPI_STORE) && tiles_n % WC == 0 && per == 32 && !a.rev && tiles_m >= 8 * WR;
+  const int n_rg = (tiles_m + WR - 1) / WR;
+  const int ntiles = walk ? n_rg * WR * tiles_n : tiles_m * tiles_n;
+#else
+  const int ntiles = tiles_m * tiles_n;
+#endif
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
   const int first = xcd * per + jb;
   const int stride = 8 * per;
@@ -179,9 +195,19 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
   // a.rev: the tile walk runs from the LAST row block to the first (tile t of the walk is tile ntiles-1-t of the matrix): the
   // kernel then starts on the rows its producer wrote last, which may still sit in the 256 MiB Infinity Cache (zkast.hip
   // alternates the direction along the kernel chain)
+#if ZK_C8_WALK
+  auto phys = [&](int t) __attribute__((always_inline)) {
+    if (!walk) return a.rev ? ntiles - 1 - t : t;
+    const int sp = t >> 5, j = t & 31, cg = sp / n_rg, rg = sp - cg * n_rg;
+    return (rg * WR + j / WC) * tiles_n + cg * WC + j % WC;
+  };
+  auto ld_row = [&](int tm) __attribute__((always_inline)) { return (tm < tiles_m ? tm : tiles_m - 1) * BM; };
+#else
   auto phys = [&](int t) __attribute__((always_inline)) { return a.rev ? ntiles - 1 - t : t; };
+  auto ld_row = [&](int tm) __attribute__((always_inline)) { return tm * BM; };
+#endif
   int l_step = 0, l_k = 0, l_ord = 0, l_tile = first;
-  int l_m0 = (phys(first) / tiles_n) * BM, l_n0 = (phys(first) % tiles_n) * BN;
+  int l_m0 = ld_row(phys(first) / tiles_n), l_n0 = (phys(first) % tiles_n) * BN;
   // ONE per-lane offset serves every piece: piece q of either operand covers rows q·64 + wave·8 + srow of the tile, and
   // the swizzled chunk ((row >> 1) & 7 does not depend on q), so q moves into the wave-uniform base address.  (Rows >= M
   // of the last row block are read as they lie — the planes hold whole 256-row tiles, zk_gemm_args — and never stored.)
@@ -302,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm_c8_kernel(const zk_gemm_args a) {
       if (++l_k == nk) {
         l_k = 0; ++l_ord; l_tile += stride;
         const int pt = phys(l_tile), tm = pt / tiles_n;
-        l_m0 = tm * BM; l_n0 = (pt - tm * tiles_n) * BN;
+        l_m0 = ld_row(tm); l_n0 = (pt - tm * tiles_n) * BN;
       }
     }
   };

@@ -100,7 +100,11 @@ int zkp_bench_gemm_c8(int M, int N, int K, int epi, int variants, int iters, int
   hipStream_t s;
   CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   // x planes hold whole 256-row tiles (the kernels read rows >= M of the last tile and never store them)
-  const size_t nx = (size_t)((M + 255) / 256 * 256) * K, nw = (size_t)N * K, no = (size_t)M * N;
+  // ZKP_TILED=1: the launch form the forward uses (zk_planes::tiled: X read as k-slice-major tiles, the GELU epilogue writes
+  // them) on the same random buffers — a permutation of random data is random data, so timing, clock and traffic are those of
+  // the production launch (the values are not compared with a row-major result)
+  const bool tiled = getenv("ZKP_TILED") != nullptr;
+  const size_t nx = (size_t)((M + 255) / 256 * 256) * K, nw = (size_t)N * K, no = (size_t)(tiled ? (M + 255) / 256 * 256 : M) * N;
   float *fx, *fw, *bias, *resid[2] = {nullptr, nullptr};
   half_t *xh, *xl, *wh, *wl, *oh[2] = {nullptr, nullptr}, *ol[2] = {nullptr, nullptr};
   CK(hipMalloc((void**)&fx, nx * 4)); CK(hipMalloc((void**)&fw, nw * 4)); CK(hipMalloc((void**)&bias, (size_t)N * 4));
@@ -129,6 +133,7 @@ int zkp_bench_gemm_c8(int M, int N, int K, int epi, int variants, int iters, int
     a.x_hi = xh; a.x_lo = xl; a.w_hi = wh; a.w_lo = wl; a.bias = bias; a.x_rowexp = nullptr; a.M = M; a.N = N; a.K = K; a.x_rows = (M + 255) / 256 * 256;
     a.o_hi = oh[v]; a.o_lo = ol[v]; a.resid = resid[v]; a.pos = nullptr; a.lo_n_limit = N; a.lo_c8_to = epi == ZK_EPI_STORE ? (2 * N) / 3 : 1 << 30;
     a.w_exp = w_exp; a.lo_c8_from = epi == ZK_EPI_STORE ? N / 3 : 1 << 30;
+    a.x_tiled = tiled ? 1 : 0; a.o_tiled = (tiled && epi == ZK_EPI_GELU) ? 1 : 0;
     return a;
   };
   auto launch = [&](int v) {
