@@ -80,6 +80,14 @@ int zk_set_prune_last_layer(zk_ctx* ctx, int enable);
  * to forwards from the feature slot (zk_logmel / zk_features_set / zk_two_stage), never to caller-provided
  * input_values.  Default on; results are bit-identical.                                                            */
 int zk_set_layer0_reuse(zk_ctx* ctx, int enable);
+/* ... and their ATTENTION state: the scores of the constant queries against the constant keys do not depend on the window
+ * either, so the running softmax state (max, sum, unnormalised output) of every constant query over the first 1024 constant
+ * keys is tabulated once per model; per window the constant queries only add the remaining 190 keys, the 120 real queries
+ * see all 1214 keys in the order [constant | real] (0.27 M instead of 1.47 M query-key pairs per window and head in layer 0,
+ * eager_attention_forward, modeling_audio_spectrogram_transformer.py:102-127).  The algorithm is exact; the keys are summed in
+ * another order than the plain kernel's, so logits agree with it to rounding (~1e-6), not bit for bit.  Only together with
+ * zk_set_layer0_reuse, for 51..100-frame windows, in the split compute modes.  Default on.                            */
+int zk_set_layer0_attention(zk_ctx* ctx, int enable);
 int zk_set_micro_batch(zk_ctx* ctx, int32_t windows); /* forward is chunked into micro-batches; 0 = auto (default)    */
 const char* zk_version(void);
 

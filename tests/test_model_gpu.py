@@ -286,11 +286,13 @@ def test_layer0_constant_row_reuse_is_exact(mode):
     """zk_set_layer0_reuse: 1094 of a 1 s window's 1214 tokens enter layer 0 with window-independent values; their
     embedding, LayerNorm-1 and q|k|v rows come from a per-model table.  Everything downstream must be bit-identical to
     computing them: the residual stream after the embeddings and after layers 0 and 5 (all 1214 rows), the logits, with a
-    window index list, across micro-batch splits, after a change of the extractor statistics or of the compute mode."""
+    window index list, across micro-batch splits, after a change of the extractor statistics or of the compute mode.
+    (Rows only: the constant-row ATTENTION state sums the keys in another order and has its own test below.)"""
     from zkast import lib, synth
     model, _ = _model(31, "sens", 0)
     model.set_compute_mode(mode)
     ctx = lib.get_context(0)
+    ctx.set_layer0_attention(False)
     rec = synth.synth_recording(19, 16000 + 20 * 8000)
     ctx.logmel(rec, rec.size, 0, 8000, 16000, 21)
     idx = np.array([20, 3, 3, 11, 0], np.int32)
@@ -325,8 +327,96 @@ def test_layer0_constant_row_reuse_is_exact(mode):
         assert np.array_equal(model.forward_from_slot(21), on[("logits", 0)])
     finally:
         ctx.set_layer0_reuse(True)
+        ctx.set_layer0_attention(True)
         ctx.set_micro_batch(0)
         ctx.debug_tap(-2)
+        model.set_compute_mode("f16c8")
+
+
+@pytest.mark.parametrize("mode", ["f16c8", "f16x3", "f16mix"])
+def test_layer0_constant_row_attention(mode, golden_dir):
+    """zk_set_layer0_attention: the constant queries of layer 0 continue from a per-model softmax state over the constant keys and
+    only see the window's real keys, the real queries see the keys in the order [constant | real].  Exact algorithm, other
+    summation order: against the plain kernel the residual stream after layer 0 and the logits agree to the rounding of the
+    fp16 softmax weights; against real transformers the error stays what it was; the launch is deterministic and invariant
+    under micro-batch splits and window index lists like every other kernel of the forward."""
+    from zkast import lib, synth
+    model, _ = _model(31, "sens", 0)
+    model.set_compute_mode(mode)
+    ctx = lib.get_context(0)
+    g = np.load(os.path.join(golden_dir, "model_sens.npz"))
+    wins = synth.golden_windows()
+    rec = np.concatenate([np.concatenate(list(wins)), synth.synth_recording(19, 16 * 16000)])
+    n = 22
+    ctx.logmel(rec, rec.size, 0, 16000, 16000, n)
+    idx = np.array([20, 3, 3, 11, 0], np.int32)
+    try:
+        res = {}
+        for att in (False, True):
+            ctx.set_layer0_attention(att)
+            ctx.debug_tap(0)
+            lg = model.forward_from_slot(n)
+            res[att] = (lg, ctx.debug_get_tap(6))
+            ctx.debug_tap(-2)
+        (l_off, t_off), (l_on, t_on) = res[False], res[True]
+        scale = np.abs(t_off).max()
+        d_tap, d_log = np.abs(t_on - t_off).max() / scale, np.abs(l_on - l_off).max()
+        e_off, e_on = np.abs(l_off[:6] - g["sens_logits"]).max(), np.abs(l_on[:6] - g["sens_logits"]).max()
+        print(f"[l0 attention {mode}] residual after layer 0: {d_tap:.2e} of max|h|, logits {d_log:.2e}; vs transformers fp32: plain {e_off:.2e}, "
+              f"constant-row state {e_on:.2e}")
+        assert not np.array_equal(t_on, t_off)      # (the path is really taken)
+        assert d_tap <= 3e-4 and d_log <= 1e-3      # (sens turns 3e-5 of the layer-0 residual into 5e-4 of a logit: what makes it the set that bites)
+        assert e_on <= 1e-3 and e_on <= e_off + 1.5e-4
+        ref_tok = g["sens_layer0_tok"]
+        assert np.abs(t_on[:, g["tokens"]] - ref_tok).max() <= 2e-4 * np.abs(ref_tok).max()
+        # deterministic, micro-batch-invariant, index lists, the cascade's compacted stage-2 call
+        assert np.array_equal(model.forward_from_slot(n), l_on)
+        for mb in (1, 4, 21):
+            ctx.set_micro_batch(mb)
+            assert np.array_equal(model.forward_from_slot(n), l_on), mb
+        ctx.set_micro_batch(0)
+        assert np.array_equal(model.forward_from_slot(0, idx), l_on[idx])
+        # another pad value rebuilds table and state
+        ctx.set_fx(0, -6.5, 2.75)
+        a = model.forward_from_slot(n)
+        ctx.set_layer0_attention(False)
+        assert 0 < np.abs(a - model.forward_from_slot(n)).max() <= 1e-3
+        ctx.set_layer0_attention(True)
+        ctx.set_fx(0, -1.1509622, 3.5340312)
+        assert np.array_equal(model.forward_from_slot(n), l_on)
+    finally:
+        ctx.set_layer0_attention(True)
+        ctx.set_micro_batch(0)
+        ctx.debug_tap(-2)
+        model.set_compute_mode("f16c8")
+
+
+def test_layer0_attention_other_frame_counts_and_single_pass():
+    """6..10 real time patches per frequency row (51..100 frames) take the constant-row attention, everything else and the
+    single-pass mode the plain kernel"""
+    from zkast import lib, synth
+    model, _ = _model(12, "init", 0)
+    ctx = lib.get_context(0)
+    try:
+        for win, frames, taken in ((10080, 61, True), (8400, 51, True), (8240, 50, False)):
+            rec = synth.synth_recording(35, win * 3)
+            ctx.logmel(rec, rec.size, 0, win, win, 3)
+            assert ctx.features_shape() == (3, frames)
+            ctx.set_layer0_attention(False)
+            ref = model.forward_from_slot(3)
+            ctx.set_layer0_attention(True)
+            got = model.forward_from_slot(3)
+            assert np.abs(got - ref).max() <= 1e-4
+            assert np.array_equal(got, ref) != taken, (frames, taken)
+        model.set_compute_mode("f16")
+        rec = synth.synth_recording(35, 16000 * 3)
+        ctx.logmel(rec, rec.size, 0, 16000, 16000, 3)
+        ctx.set_layer0_attention(False)
+        ref = model.forward_from_slot(3)
+        ctx.set_layer0_attention(True)
+        assert np.array_equal(model.forward_from_slot(3), ref)
+    finally:
+        ctx.set_layer0_attention(True)
         model.set_compute_mode("f16c8")
 
 

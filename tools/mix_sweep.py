@@ -1,7 +1,7 @@
 """Which kernel groups have to run f16x3 for the f16mix mode to keep its margin: stage-1 logit error of a list of
 assignments on N windows of the input-sensitive `sens` set, against the fp32 torch-CPU restatement (oracle/ast_torch_cpu.py,
 pinned to transformers) or, with --golden, against tests/golden/sens_tail.npz (real transformers, 3 599 windows).
-usage: python tools/mix_sweep.py [N=320] [--golden] 'spec' 'spec' ...   spec = '' (all c8) | '0' | '0:qkv+att,1:mlp' | 'x3'"""
+usage: python tools/mix_sweep.py [N=<windows, default 320>] [--golden] 'spec' 'spec' ...   spec = '' (all c8) | '0' | '0:qkv+att,1:mlp' | 'x3'"""
 import json
 import os
 import sys
@@ -28,8 +28,10 @@ def parse(spec):
 def main():
     args = [a for a in sys.argv[1:] if a != "--golden"]
     golden = "--golden" in sys.argv
-    n = int(args[0]) if args and args[0].isdigit() else 320
-    specs = [a for a in args if not a.isdigit()] or ["", "0", "x3"]
+    n = 320
+    if args and args[0].startswith("N="):
+        n = int(args.pop(0)[2:])
+    specs = args or ["", "0", "x3"]
     sd = synth.make_ast_weights(31, "sens")
     if golden:
         g = np.load(os.path.join(ROOT, "tests", "golden", "sens_tail.npz"))

@@ -53,7 +53,33 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int S_ = ZK_SEQ;
 constexpr int QKV_LD = 3 * ZK_HIDDEN;   // 2304
 constexpr int KT = 64;                  // keys per tile
-constexpr int NKT = (S_ + KT - 1) / KT; // 19
+constexpr int NKT_FULL = (S_ + KT - 1) / KT; // 19
+// ---- generalised launches (layer-0 constant-row attention, zkast.hip) ----
+// VAR 0 is the ordinary launch: 1214 queries x 1214 keys of every window, rows in token order.  VAR >= 1 reads its key
+// tiles from TWO sources — tiles [0, seg) from planes shared by all windows (source A: the layer-0 table in constant-token
+// order), the others from the window's own planes (source B, b_rows rows per window) —, may take its query rows from A, masks
+// keys >= n_keys, maps output row r to a token (out_map), and may start from (VAR 2) or dump (VAR 3) the running softmax
+// state (O[64] unnormalised, m, l per head and query row).  All sources hold whole 64-row tiles (no clamping of the last one).
+struct att_ext {
+  const half_t* a_hi; const half_t* a_lo;
+  float* state;        // [ZK_HEADS][state_rows][ST_LD] fp32
+  int seg, a_row0;     // key tile kt < seg: rows a_row0 + kt*64 of A; kt >= seg: rows (kt - seg)*64 of the window's planes
+  int a_q_row0;        // q_from_a: query row r is row a_q_row0 + r of A
+  int b_rows;          // rows per window of the per-window planes (1214 for VAR 0)
+  int n_keys;          // valid keys
+  int n_q, q_lo;       // query rows per (window, head); rows q_lo <= r < n_q produce output
+  int q_from_a;
+  int out_map;         // 1: r = constant token r (0, 1, then (f, t >= tr) ascending); 2: r - q_lo = real token f*tr + t
+  int tr;              // real time patches per frequency row (layer-0 reuse: 10)
+  int state_rows;
+};
+constexpr int ST_LD = 68;      // floats per state row: O[0..63], m, l (+2 pad)
+// token of output row r under out_map (tr real time patches per frequency row, ZK_TOUT = 101 in all)
+__device__ __forceinline__ int att_out_token(int r, int out_map, int q_lo, int tr) {
+  if (out_map == 1) { if (r < 2) return r; const int c = r - 2, nc = ZK_TOUT - tr, f = c / nc; return 2 + f * ZK_TOUT + tr + (c - f * nc); }
+  if (out_map == 2) { const int j = r - q_lo, f = j / tr; return 2 + f * ZK_TOUT + (j - f * tr); }
+  return r;
+}
 #ifndef ZK_ATT_NW
 #define ZK_ATT_NW 8      // waves per workgroup: 256 query rows share a K/V tile; ONE workgroup per CU (the split modes' four
                          // images in 3-deep rings are 96 KiB), half the staging pieces per wave of the 4-wave form (same speed)
@@ -70,11 +96,13 @@ constexpr int NVS = ZK_ATT_STAGGER ? 4 : 3;      // V ring slots (the late waves
 constexpr int QT = 32 * NW;             // query rows per workgroup
 constexpr int TILE_B = KT * 128;        // bytes of one [64][64] fp16 image
 
-template <int NSPLIT>
+template <int NSPLIT, int NKT, int VAR>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __restrict__ qkv_hi,
                                                         const half_t* __restrict__ qkv_lo, half_t* __restrict__ o_hi,
                                                         half_t* __restrict__ o_lo, int n_windows, int q_tiles, int lo_fmt, int row_limit, int rev,
-                                                        int o_tiled) {
+                                                        int o_tiled, const att_ext x) {
+  constexpr bool GEN = VAR != 0, INIT = VAR == 2, DUMP = VAR == 3;
+  static_assert(!GEN || !ZK_ATT_PERSIST, "the generalised launches exist in the non-persistent form only");
   constexpr bool SPLIT = (NSPLIT >= 2);
   constexpr bool C8 = (NSPLIT == 2);
   // LDS images of one 64-key tile: K: Kh, [Kl | Kc8]; V: Vh, [Vl].  Vl = fp16(v - fp16(v)), the lo plane the QKV epilogue
@@ -100,11 +128,14 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   // index mod 8 under round-robin placement: speed only) owns a contiguous share of the nwg items.
   const int nwg = q_tiles * ZK_HEADS * n_windows;
   int qt, head;
-  size_t tok0;
+  size_t tok0;      // first token row of the window in the OUTPUT planes (and, VAR 0, in the q|k|v planes)
+  size_t brow0 = 0; // GEN: first row of the window in its own q|k|v planes
+  const int n_q = GEN ? x.n_q : S_;      // query rows per (window, head)
   auto set_item = [&](int wg) __attribute__((always_inline)) {
     qt = wg % q_tiles;
     head = (wg / q_tiles) % ZK_HEADS;
     tok0 = (size_t)(wg / (q_tiles * ZK_HEADS)) * S_;
+    if constexpr (GEN) brow0 = (size_t)(wg / (q_tiles * ZK_HEADS)) * x.b_rows;
   };
 #if ZK_ATT_PERSIST
   // Persistent form: the workgroup walks items j, j + per, j + 2 per, ... of its XCD's share (at any moment the CUs of an
@@ -138,12 +169,17 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     int ln;      // (read here, not taken from the kernel's `lane`: see the output path)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
     const int q_row = qt * QT + wave * 32 + (ln & 31);
-    const int q_ld = q_row < S_ ? q_row : S_ - 1;
-    const size_t off = (tok0 + q_ld) * QKV_LD + head * ZK_HEAD_DIM + 8 * (ln >> 5);
+    const int q_ld = q_row < n_q ? q_row : n_q - 1;
+    size_t off = (tok0 + q_ld) * QKV_LD + head * ZK_HEAD_DIM + 8 * (ln >> 5);
+    const half_t *qsh = qkv_hi, *qsl = qkv_lo;
+    if constexpr (GEN) {
+      off = ((x.q_from_a ? (size_t)x.a_q_row0 : brow0) + q_ld) * QKV_LD + head * ZK_HEAD_DIM + 8 * (ln >> 5);
+      if (x.q_from_a) { qsh = x.a_hi; qsl = x.a_lo; }
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qraw_h[ks] = *(const h8_t*)(qkv_hi + off + ks * 16);
-      if constexpr (SPLIT) qraw_l[ks] = *(const h8_t*)(qkv_lo + off + ks * 16);
+      qraw_h[ks] = *(const h8_t*)(qsh + off + ks * 16);
+      if constexpr (SPLIT) qraw_l[ks] = *(const h8_t*)(qsl + off + ks * 16);
     }
   };
   q_issue();
@@ -192,7 +228,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     koff[u] = (unsigned)row * (unsigned)(QKV_LD * 2) + kc;
     voff[u] = (unsigned)row * (unsigned)(QKV_LD * 2) + vc;
     int key = (NKT - 1) * KT + row;      // last tile: keys >= 1214 (masked later) re-read key 1213
-    key = key < S_ ? key : S_ - 1;
+    if constexpr (!GEN) key = key < S_ ? key : S_ - 1;      // (GEN: the sources hold whole tiles)
     const unsigned rl = (unsigned)(key - (NKT - 1) * KT) * (unsigned)(QKV_LD * 2);
     koff_last[u] = rl + kc;
     voff_last[u] = rl + vc;
@@ -219,8 +255,14 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     kt = kt < NKT - 1 ? kt : NKT - 1;
     const bool last = kt == NKT - 1;
     const int u = pc % PPI, img = isk ? pc / PPI : pc / PPI - NKIMG;      // image 0 = hi plane, 1 = lo plane
-    const size_t tb = ((tok0 + (size_t)kt * KT) * QKV_LD + head * ZK_HEAD_DIM) * 2;     // bytes
-    const char* src = (img == 1 ? (const char*)qkv_lo : (const char*)qkv_hi) + tb + (isk ? 1 : 2) * ZK_HIDDEN * 2;
+    size_t tb = ((tok0 + (size_t)kt * KT) * QKV_LD + head * ZK_HEAD_DIM) * 2;     // bytes
+    const char* src = (img == 1 ? (const char*)qkv_lo : (const char*)qkv_hi);
+    if constexpr (GEN) {
+      const bool from_a = kt < x.seg;
+      tb = (((from_a ? (size_t)x.a_row0 + (size_t)kt * KT : brow0 + (size_t)(kt - x.seg) * KT)) * QKV_LD + head * ZK_HEAD_DIM) * 2;
+      if (from_a) src = (img == 1 ? (const char*)x.a_lo : (const char*)x.a_hi);
+    }
+    src += tb + (isk ? 1 : 2) * ZK_HIDDEN * 2;
     char* base = isk ? smem + sk * KBUF_B + img * TILE_B : smem + V_OFF + sv * VBUF_B + img * TILE_B;
     const unsigned o = isk ? (last ? koff_last[u] : koff[u]) : (last ? voff_last[u] : voff[u]);
     dma(uniform_ptr(src), o, base + (wave + NW * u) * 1024);
@@ -392,7 +434,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   };
   kv_prologue();
   for (;;) {      // one item per pass (ZK_ATT_PERSIST = 0: a single pass)
-  wave_active = __builtin_amdgcn_readfirstlane(qt * QT + wave * 32) < (row_limit < S_ ? row_limit : S_);
+  wave_active = __builtin_amdgcn_readfirstlane(qt * QT + wave * 32) < (row_limit < n_q ? row_limit : n_q);
 #pragma unroll
   for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; negm[i] = 0.f; }
   m_run = 0.f; l_run = 0.f;
@@ -400,6 +442,27 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   q_prepare();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (INIT) {      // start from the tabulated state of this (head, query row): O (unnormalised), m, l over the keys it covers
+    if (wave_active) {
+      int ln;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      int row = qt * QT + wave * 32 + (ln & 31);
+      row = row < n_q ? row : n_q - 1;
+      const float* st = x.state + ((size_t)head * x.state_rows + row) * ST_LD;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const f4_t v = *(const f4_t*)(st + 32 * mb + 8 * rg + 4 * (ln >> 5));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) oacc[mb][4 * rg + j] = v[j];
+        }
+      m_run = st[64];
+      l_run = (ln >> 5) == 0 ? st[65] : 0.f;      // (l_run is a per-half partial sum; the table holds the row's total)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[i] = -m_run;
+    }
+  }
 
   // row maximum of a score tile (in-lane over the 32 keys, then across the two half-waves)
   auto row_max = [&](f16_t (&sc)[2]) __attribute__((always_inline)) {
@@ -450,7 +513,14 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       mma_group(gc, sA);
     });
     mx = row_max(sA);
-    rescale(sA, mx, 1.0f);      // first tile: the running max starts at its row maximum
+    if constexpr (INIT) {      // a reference exists already (the state's): it moves by the deferred-rescale rule, O and l follow
+      if (!__all(mx <= RESCALE_THR)) {
+        const float delta = fmaxf(mx, 0.f);
+        rescale(sA, delta, __builtin_amdgcn_exp2f(-delta));
+      }
+    } else {
+      rescale(sA, mx, 1.0f);      // first tile: the running max starts at its row maximum
+    }
     mx = 0.f;
   }
   __syncthreads();      // K(0) has been read by every wave: iteration 0 overwrites its slot
@@ -523,7 +593,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
               const int kbn = e >> 4, r = e & 15;
               if constexpr (MASKNEXT) {
                 const int key = (NKT - 1) * KT + kbn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (key >= S_) sn[kbn][r] = -1e30f;
+                if (key >= (GEN ? x.n_keys : S_)) sn[kbn][r] = -1e30f;
               }
               mxp = fmaxf(mxp, sn[kbn][r]);
             }
@@ -615,7 +685,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
             const int kbn = e >> 4, r = e & 15;
             if constexpr (FINAL) {
               const int key = (NKT - 1) * KT + kbn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              if (key >= S_) sc[kbn][r] = -1e30f;
+              if (key >= (GEN ? x.n_keys : S_)) sc[kbn][r] = -1e30f;
             }
             mxp = fmaxf(mxp, sc[kbn][r]);
           }
@@ -711,8 +781,20 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   int ln;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
   const int rd_row = ln >> 3, rd_ch = ln & 7, e_half = ln >> 5, e_row = ln & 31;
-  const bool act = wave_active && (!(ZK_ATT_ABL & 16) || lo_fmt == 12345);      // (16: a never-true runtime test keeps the work alive)
+  const bool act = wave_active && !DUMP && (!(ZK_ATT_ABL & 16) || lo_fmt == 12345);      // (16: a never-true runtime test keeps the work alive)
   const int row_base = qt * QT + wave * 32;
+  if constexpr (DUMP) {      // the running state instead of the normalised output (layer-0 table: constant queries over constant keys)
+    const int row = row_base + e_row;
+    if (wave_active && row < n_q) {
+      float* st = x.state + ((size_t)head * x.state_rows + row) * ST_LD;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *(f4_t*)(st + 32 * mb + 8 * rg + 4 * e_half) = f4_t{oacc[mb][4 * rg], oacc[mb][4 * rg + 1], oacc[mb][4 * rg + 2], oacc[mb][4 * rg + 3]};
+      if (e_half == 0) { st[64] = m_run; st[65] = l_tot; }
+    }
+  }
   const size_t orow0 = (tok0 + (size_t)row_base) * ZK_HIDDEN + head * ZK_HEAD_DIM;
 #if ZK_ATT_PERSIST
   // next item: its q loads and K/V prologue pieces go out in front of this item's stores.  The barrier: every wave is past
@@ -738,9 +820,20 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
 #else
       // (o_tiled: the output planes are the O projection's X operand in k-slice-major tiles, zk_planes::tiled — the head's 64
       // columns are one chunk, eight consecutive rows of it 1 KiB contiguous)
-      const size_t oo = o_tiled ? zk_tiled_off((int)(tok0 + row_base + r), head * ZK_HEAD_DIM + rd_ch * 8, ZK_HIDDEN)
-                                : orow0 + (size_t)r * ZK_HIDDEN + rd_ch * 8;
-      if (row_base + r < S_) *(h8_t*)(plane + oo) = v;
+      size_t oo;
+      bool valid;
+      if constexpr (GEN) {      // output row -> token of the window (att_out_token)
+        const int row = row_base + r;
+        valid = row >= x.q_lo && row < n_q;
+        const size_t trow = tok0 + (size_t)att_out_token(valid ? row : x.q_lo, x.out_map, x.q_lo, x.tr);
+        oo = o_tiled ? zk_tiled_off((int)trow, head * ZK_HEAD_DIM + rd_ch * 8, ZK_HIDDEN)
+                     : trow * ZK_HIDDEN + head * ZK_HEAD_DIM + rd_ch * 8;
+      } else {
+        valid = row_base + r < S_;
+        oo = o_tiled ? zk_tiled_off((int)(tok0 + row_base + r), head * ZK_HEAD_DIM + rd_ch * 8, ZK_HIDDEN)
+                     : orow0 + (size_t)r * ZK_HIDDEN + rd_ch * 8;
+      }
+      if (valid) *(h8_t*)(plane + oo) = v;
 #endif
     }
   };
@@ -804,7 +897,8 @@ void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit
 #else
     const int pgrid = grid;
 #endif
-    hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(64 * NW), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, wg_tiles, out.lo_fmt, row_limit, rev, out.tiled);
+    hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(64 * NW), lds, s, qkv.hi, qkv.lo, out.hi, out.lo, n_windows, wg_tiles, out.lo_fmt, row_limit, rev, out.tiled,
+                       att_ext{});
   };
 #ifdef ZK_ATT_NO_VL
   constexpr int NIMG_SPLIT = 3;
@@ -813,7 +907,47 @@ void zk_launch_attention(zk_planes qkv, zk_planes out, int n_windows, int nsplit
 #endif
   // (K ring of 3 slots x 2 images in the split modes, V ring of NVS slots x (NIMG_SPLIT - 2) images, output staging strip)
   constexpr int STG_B = NW * 32 * 144;
-  if (nsplit == 2) go(attention_kernel<2>, (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B + STG_B);
-  else if (nsplit == 3) go(attention_kernel<3>, (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B + STG_B);
-  else go(attention_kernel<1>, (3 + NVS) * TILE_B + STG_B);
+  if (nsplit == 2) go(attention_kernel<2, NKT_FULL, 0>, (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B + STG_B);
+  else if (nsplit == 3) go(attention_kernel<3, NKT_FULL, 0>, (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B + STG_B);
+  else go(attention_kernel<1, NKT_FULL, 0>, (3 + NVS) * TILE_B + STG_B);
+}
+
+// layer-0 constant-row attention: the three generalised launches (zk_common.h)
+void zk_launch_attention_l0(int what, zk_planes ctab, float* state, zk_planes tail, zk_planes out, int n_windows, int t_real,
+                            int nsplit, hipStream_t s) {
+  if (what != ZK_L0_ATT_DUMP && n_windows <= 0) return;
+  const int n_real = ZK_FOUT * t_real, n_const = S_ - n_real, rem = n_const - 1088;
+  att_ext x{};
+  x.a_hi = ctab.hi; x.a_lo = ctab.lo; x.state = state; x.tr = t_real; x.state_rows = n_const; x.b_rows = 128;
+  int nq, nw = n_windows;
+  if (what == ZK_L0_ATT_DUMP) {           // 17 tiles of the table, keys 0..1023 valid (the 17th tile is masked: odd tile count)
+    x.seg = 17; x.a_row0 = 0; x.n_keys = 1024; x.q_from_a = 1; x.a_q_row0 = 0; x.n_q = nq = n_const; x.q_lo = 0; x.out_map = 1; nw = 1;
+  } else if (what == ZK_L0_ATT_CONST) {   // table rows 1024..1087, then the window's tail: rem constant + n_real real keys
+    x.seg = 1; x.a_row0 = 1024; x.n_keys = 64 + rem + n_real; x.q_from_a = 1; x.a_q_row0 = 0; x.n_q = nq = n_const; x.q_lo = 0; x.out_map = 1;
+  } else {                                // all keys in the order [constant | real]; the queries are the tail's real rows
+    x.seg = 17; x.a_row0 = 0; x.n_keys = S_; x.q_from_a = 0; x.n_q = nq = rem + n_real; x.q_lo = rem; x.out_map = 2;
+  }
+  const int wg_tiles = (nq + QT - 1) / QT;
+  const int grid = wg_tiles * ZK_HEADS * nw;
+#ifdef ZK_ATT_NO_VL
+  constexpr int NIMG_SPLIT = 3;
+#else
+  constexpr int NIMG_SPLIT = 4;
+#endif
+  constexpr int STG_B = NW * 32 * 144, LDS = (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B + STG_B;
+  auto go = [&](auto kernel) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * NW), LDS, s, tail.hi, tail.lo, out.hi, out.lo, nw, wg_tiles, out.lo_fmt, nq, 0, out.tiled, x);
+  };
+#if !ZK_ATT_PERSIST
+  if (nsplit == 2) {
+    if (what == ZK_L0_ATT_DUMP) go(attention_kernel<2, 17, 3>);
+    else if (what == ZK_L0_ATT_CONST) go(attention_kernel<2, 3, 2>);
+    else go(attention_kernel<2, NKT_FULL, 1>);
+  } else {
+    if (what == ZK_L0_ATT_DUMP) go(attention_kernel<3, 17, 3>);
+    else if (what == ZK_L0_ATT_CONST) go(attention_kernel<3, 3, 2>);
+    else go(attention_kernel<3, NKT_FULL, 1>);
+  }
+#endif
 }

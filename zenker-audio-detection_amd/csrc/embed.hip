@@ -173,7 +173,70 @@ __global__ __launch_bounds__(320) void l0_assemble_qkv_kernel(const half_t* __re
   }
 }
 
+// ---- layer-0 constant-row ATTENTION (attention.hip: att_ext; zkast.hip) -------------------------------------------------
+// constant-order table: row c of the output = q|k|v row of constant token c (0, 1, then (f, t >= t_real) ascending) of the
+// natural-order table planes; rows n_const .. rows_pad-1 are zero (whole 64-row tiles, finite values behind masked keys)
+__global__ __launch_bounds__(320) void l0_const_order_kernel(const half_t* __restrict__ t_hi, const half_t* __restrict__ t_lo,
+                                                             half_t* __restrict__ o_hi, half_t* __restrict__ o_lo, int t_real, int n_const) {
+  constexpr int CH = 3 * ZK_HIDDEN / 8, LD = 3 * ZK_HIDDEN;
+  const int c = blockIdx.x, ch = threadIdx.x;
+  if (ch >= CH) return;
+  h8_t vh = {}, vl = {};
+  if (c < n_const) {
+    int row = c;
+    if (c >= 2) { const int j = c - 2, tpad = ZK_TOUT - t_real, f = j / tpad; row = 2 + f * ZK_TOUT + t_real + (j - f * tpad); }
+    vh = *(const h8_t*)(t_hi + (size_t)row * LD + ch * 8);
+    if (t_lo) vl = *(const h8_t*)(t_lo + (size_t)row * LD + ch * 8);
+  }
+  *(h8_t*)(o_hi + (size_t)c * LD + ch * 8) = vh;
+  if (o_lo) *(h8_t*)(o_lo + (size_t)c * LD + ch * 8) = vl;
+}
+
+// per-window TAIL planes [n_windows][128][2304]: rows 0 .. rem-1 = the last `rem` constant rows (rows 1088 .. of the
+// constant-order table), rows rem .. rem + 12·t_real - 1 = the window's real rows (compact [b][f][t < t_real] planes of the
+// layer-0 QKV GEMM), the rest zero.  One workgroup = one tail row of ZK_L0_WPB consecutive windows.
+__global__ __launch_bounds__(320) void l0_tail_kernel(const half_t* __restrict__ r_hi, const half_t* __restrict__ r_lo,
+                                                      const half_t* __restrict__ c_hi, const half_t* __restrict__ c_lo,
+                                                      half_t* __restrict__ o_hi, half_t* __restrict__ o_lo, int n_windows, int t_real, int rem) {
+  constexpr int CH = 3 * ZK_HIDDEN / 8, LD = 3 * ZK_HIDDEN;
+  const int row = blockIdx.x % 128, b0 = (blockIdx.x / 128) * ZK_L0_WPB;
+  const int ch = threadIdx.x;
+  if (ch >= CH) return;
+  const int n_real = ZK_FOUT * t_real;
+  h8_t vh = {}, vl = {};
+  if (row < rem) {
+    vh = *(const h8_t*)(c_hi + (size_t)(1088 + row) * LD + ch * 8);
+    if (o_lo) vl = *(const h8_t*)(c_lo + (size_t)(1088 + row) * LD + ch * 8);
+  }
+  const bool real = row >= rem && row < rem + n_real;
+#pragma unroll 4
+  for (int w = 0; w < ZK_L0_WPB; ++w) {
+    const int b = b0 + w;
+    if (b >= n_windows) break;
+    if (real) {
+      const size_t r = (size_t)b * n_real + (row - rem);
+      vh = *(const h8_t*)(r_hi + r * LD + ch * 8);
+      if (o_lo) vl = *(const h8_t*)(r_lo + r * LD + ch * 8);
+    }
+    const size_t oo = ((size_t)b * 128 + row) * LD + ch * 8;
+    *(h8_t*)(o_hi + oo) = vh;
+    if (o_lo) *(h8_t*)(o_lo + oo) = vl;
+  }
+}
+
 }  // namespace
+
+void zk_launch_l0_const_order(zk_planes table, zk_planes out, int t_real, int rows_pad, hipStream_t s) {
+  const int n_const = 2 + ZK_FOUT * (ZK_TOUT - t_real);
+  hipLaunchKernelGGL(l0_const_order_kernel, dim3((unsigned)rows_pad), dim3(320), 0, s, table.hi, table.lo, out.hi, out.lo, t_real, n_const);
+}
+
+void zk_launch_l0_tail(zk_planes real_rows, zk_planes ctab, zk_planes out, int n_windows, int t_real, hipStream_t s) {
+  if (n_windows <= 0) return;
+  const int rem = 2 + ZK_FOUT * (ZK_TOUT - t_real) - 1088;
+  hipLaunchKernelGGL(l0_tail_kernel, dim3((unsigned)(((n_windows + ZK_L0_WPB - 1) / ZK_L0_WPB) * 128)), dim3(320), 0, s, real_rows.hi, real_rows.lo,
+                     ctab.hi, ctab.lo, out.hi, out.lo, n_windows, t_real, rem);
+}
 
 void zk_launch_gather_tok01(zk_planes att, const float* hidden, int n_windows, zk_planes att_out, float* hidden_out,
                             hipStream_t s) {

@@ -174,6 +174,25 @@ void zk_launch_gather_xq(zk_planes x, int n_windows, zk_planes out, hipStream_t 
 void zk_launch_scatter_q(zk_planes q, int n_windows, zk_planes qkv, hipStream_t s);
 void zk_launch_l0_fill_hidden(float* hidden, const float* table, int n_windows, int t_real, hipStream_t s);
 void zk_launch_l0_assemble_qkv(zk_planes real_rows, zk_planes table, zk_planes out, int n_windows, int t_real, hipStream_t s);
+// ---- layer-0 constant-row ATTENTION (attention.hip / embed.hip; orchestrated by zkast.hip) ----
+// With t_real real time patches per frequency row a window has n_real = 12·t_real real tokens and n_const = 1214 - n_real
+// constant ones.  The scores of constant queries against constant keys do not depend on the window, so their running softmax
+// state (O unnormalised, m, l) over the first 1024 constant keys is tabulated once per model and every window only adds
+//   * for its constant queries: constant keys 1024 .. n_const-1 and its real keys            (ZK_L0_ATT_CONST, 3 key tiles),
+//   * for its real queries: all keys, in the order [constant | real]                       (ZK_L0_ATT_REAL, 19 key tiles),
+// 0.27 M instead of 1.47 M query-key pairs per window and head.  Key tiles 0..16 are rows of the model's constant-order table
+// (shared by all windows), tiles 17..18 the window's 128-row TAIL planes (n_const - 1088 constant rows, the real rows, zero
+// padding).  Needs 1088 <= n_const < 1152 and n_const - 1088 + n_real <= 126, i.e. 6 <= t_real <= 10 (zk_l0_att_supported).
+#define ZK_L0_CTAB_ROWS 1152      // rows of the constant-order table planes (18 whole key tiles; rows >= n_const are zero)
+#define ZK_L0_STATE_LD 68         // floats per state row: O[64], m, l, 2 pad
+enum { ZK_L0_ATT_DUMP = 0, ZK_L0_ATT_CONST = 1, ZK_L0_ATT_REAL = 2 };
+inline bool zk_l0_att_supported(int t_real) { return t_real >= 6 && t_real <= 10; }
+void zk_launch_l0_const_order(zk_planes table, zk_planes out, int t_real, int rows_pad, hipStream_t s);
+void zk_launch_l0_tail(zk_planes real_rows, zk_planes ctab, zk_planes out, int n_windows, int t_real, hipStream_t s);
+// what = ZK_L0_ATT_DUMP: state of the constant queries over constant keys 0..1023 -> `state` (ctab only; n_windows ignored);
+// ZK_L0_ATT_CONST / _REAL: the two per-forward launches, output rows scattered to their tokens in `out` ([M, 768] planes)
+void zk_launch_attention_l0(int what, zk_planes ctab, float* state, zk_planes tail, zk_planes out, int n_windows, int t_real,
+                            int nsplit, hipStream_t s);
 void zk_launch_im2col_full(const float* input_values, int n_windows, zk_planes out, hipStream_t s);
 void zk_launch_cls_rows(float* hidden, const float* cls, const float* dist, const float* pos, int n_windows,
                         hipStream_t s);

@@ -83,7 +83,7 @@ struct LayerW {
 // kernel group in the 3-pass ZK_F16X3 arithmetic, a clear one in ZK_F16C8 (chosen on the input-sensitive
 // weight set so that a configs[3]-sized recording keeps >= 20 % of the 1e-3 logit tolerance)
 #ifndef ZK_MIX_X3_MASK
-#define ZK_MIX_X3_MASK 0xFull
+#define ZK_MIX_X3_MASK 0x37ull      // layer 0: QKV, QK^T, O; layer 1: QKV, QK^T (zkast/lib.py: MIX_X3_GROUPS)
 #endif
 struct LayerMode { int qkv, att, o, mlp; };
 // attention reads k's lo plane as c8 byte pairs only when the ZK_F16C8 QKV epilogue wrote them, and any lo plane only if
@@ -131,12 +131,18 @@ struct StageModel {
   float* l0_hidden = nullptr;
   half_t *l0_qkv_hi = nullptr, *l0_qkv_lo = nullptr;
   int l0_frames = -1, l0_mode = 0, l0_base = 0;
+  // layer-0 constant-row attention (zk_common.h): the table's q|k|v rows in constant-token order and the running softmax state of
+  // the constant queries over the first 1024 constant keys; l0_att: valid for the current table
+  half_t *l0_ctab_hi = nullptr, *l0_ctab_lo = nullptr;
+  float* l0_state = nullptr;
+  bool l0_att = false;
   float l0_mean = 0.f, l0_std = 0.f;
   void release() {
     for (void* p : allocs) (void)hipFree(p);
     allocs.clear();
     loaded = false;
     l0_hidden = nullptr; l0_qkv_hi = l0_qkv_lo = nullptr; l0_frames = -1;
+    l0_ctab_hi = l0_ctab_lo = nullptr; l0_state = nullptr; l0_att = false;
   }
 };
 
@@ -185,6 +191,7 @@ struct zk_ctx {
   DevBuf xq_rowexp;      // row exponents of the gathered LayerNorm rows of the pruned last layer's q GEMM (ZK_QROWS per window)
   bool prune_last = true;
   bool l0_reuse = true;      // layer-0 constant-row reuse (zk_set_layer0_reuse)
+  bool l0_attention = true;  // ... including the constant-row attention state (zk_set_layer0_attention)
   int ws_windows = 0;
   bool ws_split = false;
 
@@ -573,6 +580,21 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0
     } else
     if (int grc = run_gemm(c, P_QKV, xn, L.wqkv, L.bqkv, Mq, 3 * ZK_HIDDEN, ZK_HIDDEN, ZK_EPI_STORE, ns_q, qkv_dst,
              nullptr, nullptr, 3 * ZK_HIDDEN, k_c8 ? ZK_HIDDEN : 1 << 30, next_dir(c), 2 * ZK_HIDDEN)) return grc;
+    // layer-0 constant-row attention (zk_common.h): the constant queries continue from the model's tabulated state over the
+    // constant keys and only see the window's real keys; the real queries see all keys in the order [constant | real].  The
+    // full q|k|v planes are never assembled: the window's 128-row tail planes (in the q|k|v workspace) are all it adds.
+    const bool l0att = l0 && !last && sm.l0_att && c->l0_attention && sp_q && att_split != 1;
+    if (l0att) {
+      zk_planes ctab{sm.l0_ctab_hi, sm.l0_ctab_lo, ZK_LO_F16}, tail = qkv;
+      { ProfScope ps(c, P_EMBED); zk_launch_l0_tail(qkv_dst, ctab, tail, nb, tr, c->stream); }
+      ProfScope ps(c, P_AT);
+      const int n_real = ZK_FOUT * tr, n_const = ZK_SEQ - n_real;
+      if (c->prof) c->prof_flops[P_AT] += (double)nb * ZK_HEADS * 4.0 * ZK_HEAD_DIM *
+                                          ((double)n_const * (ZK_SEQ - 1024) + (double)n_real * ZK_SEQ);
+      (void)next_dir(c);
+      zk_launch_attention_l0(ZK_L0_ATT_CONST, ctab, sm.l0_state, tail, att, nb, tr, att_split, c->stream);
+      zk_launch_attention_l0(ZK_L0_ATT_REAL, ctab, sm.l0_state, tail, att, nb, tr, att_split, c->stream);
+    } else {
     if (l0) {
       ProfScope ps(c, P_EMBED);
       zk_planes tab{sm.l0_qkv_hi, sp_q ? sm.l0_qkv_lo : nullptr, qkv.lo_fmt};
@@ -587,6 +609,7 @@ int forward_micro(zk_ctx* c, StageModel& sm, int nb, float* d_logits, int tr = 0
       if (c->prof) c->prof_flops[P_AT] += (double)nb * ZK_HEADS * 4.0 * (last ? (q32 ? (double)ZK_QROWS : 128.0) : (double)ZK_SEQ) * ZK_SEQ * ZK_HEAD_DIM;
       zk_launch_attention(qkv, att, nb, att_split, qt, c->stream, next_dir(c));
     }
+    }      // (!l0att)
     if (last) {
       zk_planes att_s = c->att_s.get(sp_o, lof(ns_o)), xn_s = c->xn_s.get(sp_m, lof(ns_m)), mid_s = c->mid_s.get(sp_m, lof(ns_m));
       float* hs = c->hidden_s.as<float>();
@@ -675,7 +698,35 @@ int build_l0_table(zk_ctx* c, StageModel& sm, int n_frames) {
   // a one-off per model: wait for the copies, so that the table is complete whatever stream a later forward runs on
   // (zk_set_stream, async mode)
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  sm.l0_frames = n_frames; sm.l0_mode = ns * 2 + (k_c8 ? 1 : 0); sm.l0_base = nsb; sm.l0_mean = sm.mean; sm.l0_std = sm.std;
+  // constant-row attention: the table once more in constant-token order, and the state of the constant queries over the
+  // constant keys 0..1023 (computed by the attention kernel itself, so a window's launch continues exactly where it stops)
+  sm.l0_att = false;
+  const int trr = (n_frames + ZK_TSTRIDE - 1) / ZK_TSTRIDE;
+  const int am = sm.layer_mode[0].att;
+  if (sp && am != ZK_F16 && zk_l0_att_supported(trr)) {
+    if (!sm.l0_ctab_hi || !sm.l0_ctab_lo || !sm.l0_state) {
+      void* t[3] = {nullptr, nullptr, nullptr};
+      const size_t bytes[3] = {(size_t)ZK_L0_CTAB_ROWS * 3 * ZK_HIDDEN * 2, (size_t)ZK_L0_CTAB_ROWS * 3 * ZK_HIDDEN * 2,
+                               (size_t)ZK_HEADS * ZK_SEQ * ZK_L0_STATE_LD * 4};
+      bool ok = true;
+      for (int i = 0; i < 3 && ok; ++i)
+        if (hipMalloc(&t[i], bytes[i]) != hipSuccess) { (void)hipGetLastError(); for (int j = 0; j < i; ++j) (void)hipFree(t[j]); ok = false; }
+      if (ok) {
+        sm.l0_ctab_hi = (half_t*)t[0]; sm.l0_ctab_lo = (half_t*)t[1]; sm.l0_state = (float*)t[2];
+        for (void* p : t) sm.allocs.push_back(p);
+      }
+    }
+    if (sm.l0_ctab_hi && sm.l0_ctab_lo && sm.l0_state) {
+      zk_planes tabn{sm.l0_qkv_hi, sm.l0_qkv_lo, ZK_LO_F16}, ctab{sm.l0_ctab_hi, sm.l0_ctab_lo, ZK_LO_F16};
+      zk_launch_l0_const_order(tabn, ctab, trr, ZK_L0_CTAB_ROWS, c->stream);
+      zk_launch_attention_l0(ZK_L0_ATT_DUMP, ctab, sm.l0_state, zk_planes{nullptr, nullptr, 0}, zk_planes{nullptr, nullptr, 0}, 1, trr,
+                             am == ZK_F16C8 ? 2 : 3, c->stream);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      sm.l0_att = true;
+    }
+  }
+  sm.l0_frames = n_frames; sm.l0_mode = (ns * 2 + (k_c8 ? 1 : 0)) * 4 + am; sm.l0_base = nsb; sm.l0_mean = sm.mean; sm.l0_std = sm.std;
   return ZK_OK;
 }
 
@@ -710,7 +761,8 @@ int forward_device(zk_ctx* c, int stage, const float* src_full, const int32_t* d
     tr = (c->feat_frames + ZK_TSTRIDE - 1) / ZK_TSTRIDE;
     if (tr >= ZK_TOUT) tr = 0;
   }
-  if (tr && (sm.l0_frames != c->feat_frames || sm.l0_mode != sm.layer_mode[0].qkv * 2 + (sm.layer_mode[0].att == ZK_F16C8 ? 1 : 0) ||
+  if (tr && (sm.l0_frames != c->feat_frames ||
+             sm.l0_mode != (sm.layer_mode[0].qkv * 2 + (sm.layer_mode[0].att == ZK_F16C8 ? 1 : 0)) * 4 + sm.layer_mode[0].att ||
              sm.l0_base != sm.base_mode() ||
              sm.l0_mean != sm.mean || sm.l0_std != sm.std)) {
     // a table that cannot be built (out of memory) only costs the shortcut: the forward takes the ordinary path
@@ -799,6 +851,7 @@ int zk_create(int device_id, zk_ctx** out) {
   zk_ctx* c = new zk_ctx();
   if (const char* wa = getenv("ZK_WALK_ALT")) c->walk_alt = wa[0] == '1';
   if (const char* lr = getenv("ZK_L0_REUSE")) c->l0_reuse = lr[0] != '0';      // A/B switch; zk_set_layer0_reuse is the API
+  if (const char* la = getenv("ZK_L0_ATT")) c->l0_attention = la[0] != '0';    // A/B switch; zk_set_layer0_attention is the API
   c->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess) { delete c; return fail(nullptr, ZK_E_HIP, "hipSetDevice(%d) failed", device_id); }
   hipDeviceProp_t prop;
@@ -854,6 +907,7 @@ int zk_set_stream(zk_ctx* c, void* s) {
 }
 int zk_set_async(zk_ctx* c, int e) { if (!c) return ZK_E_ARG; c->async = e != 0; return ZK_OK; }
 int zk_synchronize(zk_ctx* c) { if (!c) return ZK_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return ZK_OK; }
+int zk_set_layer0_attention(zk_ctx* c, int e) { if (!c) return ZK_E_ARG; c->l0_attention = e != 0; return ZK_OK; }
 int zk_set_micro_batch(zk_ctx* c, int32_t w) {
   if (!c) return ZK_E_ARG;
   // 512 windows (M = 621,568 token rows, ~21 GB of activation planes) is the largest micro-batch the test suite runs

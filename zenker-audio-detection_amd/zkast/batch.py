@@ -11,6 +11,7 @@ import os
 from typing import Any, Dict, List, Optional
 
 from . import pipeline as pl
+from .lib import DEFAULT_COMPUTE_MODE
 
 
 def read_ids(ids_path: str) -> List[str]:
@@ -117,7 +118,7 @@ def build_arg_parser():
     ap.add_argument("--stage2-argmax", action="store_true")
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--dry-run", action="store_true")
-    ap.add_argument("--compute-mode", default="f16c8", choices=["f16", "f16c8", "f16x3"])
+    ap.add_argument("--compute-mode", default=DEFAULT_COMPUTE_MODE, choices=["f16", "f16c8", "f16x3", "f16mix"])
     return ap
 
 

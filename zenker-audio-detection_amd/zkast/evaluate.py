@@ -13,6 +13,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 from . import lib as _lib
+from .lib import DEFAULT_COMPUTE_MODE
 from .feature_extraction import ZkASTFeatureExtractor
 from .modeling import ZkASTConfig, ZkASTForAudioClassification
 from .pipeline import SAMPLING_RATE, load_audio
@@ -76,7 +77,7 @@ def softmax(logits: np.ndarray) -> np.ndarray:
     return (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
 
 
-def run_inference(model_dir: str, X: Sequence, batch_size: int, stage: int = 0, compute_mode="f16c8",
+def run_inference(model_dir: str, X: Sequence, batch_size: int, stage: int = 0, compute_mode=DEFAULT_COMPUTE_MODE,
                   device: int = 0) -> np.ndarray:
     """:163-191 — scores = softmax(logits)[:, 1] (probability of class 1) for every snippet of X."""
     feature_extractor = ZkASTFeatureExtractor.from_pretrained(model_dir, device=device)

@@ -13,6 +13,7 @@ import os
 import numpy as np
 
 from . import lib as _lib
+from .lib import DEFAULT_COMPUTE_MODE
 
 _CFG_KEYS = ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "patch_size",
              "frequency_stride", "time_stride", "max_length", "num_mel_bins", "layer_norm_eps")
@@ -95,7 +96,7 @@ class ZkASTForAudioClassification:
 
     main_input_name = "input_values"
 
-    def __init__(self, config: ZkASTConfig, state_dict: dict, stage: int = 0, compute_mode="f16c8", device: int = 0,
+    def __init__(self, config: ZkASTConfig, state_dict: dict, stage: int = 0, compute_mode=DEFAULT_COMPUTE_MODE, device: int = 0,
                  fx_mean: float = -4.2677393, fx_std: float = 4.5689974):
         self.config = config
         self.stage = int(stage)
@@ -107,7 +108,7 @@ class ZkASTForAudioClassification:
 
     @classmethod
     def from_pretrained(cls, model_root: str, config: ZkASTConfig | None = None, stage: int = 0,
-                        compute_mode="f16c8", device: int = 0, **kwargs):
+                        compute_mode=DEFAULT_COMPUTE_MODE, device: int = 0, **kwargs):
         if config is None:
             config = ZkASTConfig.from_pretrained(model_root)
         sd = _read_checkpoint(model_root)

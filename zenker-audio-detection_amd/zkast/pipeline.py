@@ -15,6 +15,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import numpy as np
 
 from . import lib as _lib
+from .lib import DEFAULT_COMPUTE_MODE
 from .feature_extraction import ZkASTFeatureExtractor
 from .modeling import ZkASTConfig, ZkASTForAudioClassification
 
@@ -118,7 +119,7 @@ def window_audio(audio: np.ndarray, window_sec: float, hop_sec: float, sr: int =
 
 
 # ----------------- Model loading -----------------
-def load_stage_model(model_root: str, label_order: List[str], stage: int = 0, compute_mode="f16c8", device: int = 0):
+def load_stage_model(model_root: str, label_order: List[str], stage: int = 0, compute_mode=DEFAULT_COMPUTE_MODE, device: int = 0):
     """(fx, model) of one stage from a local checkpoint directory, labels set from `label_order` (:86-98).  `stage`
     picks the library's weight slot (0: Idle/Swallow, 1: Healthy/Zenker); both stages stay resident side by side."""
     config = ZkASTConfig.from_pretrained(model_root)
@@ -443,7 +444,7 @@ def build_arg_parser():
     ap.add_argument("--stage2-argmax", action="store_true")
     ap.add_argument("--output-json")
     ap.add_argument("--show-first-n", type=int, default=5)
-    ap.add_argument("--compute-mode", default="f16c8", choices=["f16", "f16c8", "f16x3"])
+    ap.add_argument("--compute-mode", default=DEFAULT_COMPUTE_MODE, choices=["f16", "f16c8", "f16x3", "f16mix"])
     # the cached variant's cache options (..._cache.py:361-375); here the cache is OFF unless a directory is given — the
     # device log-mel costs 0.5 ms per 1 024 windows, the cache only matters for exchanging features with the reference
     ap.add_argument("--feature-cache-dir", default=None,
