@@ -28,7 +28,30 @@ def mfma_blocks(asm_text, min_mfma=8):
     return out
 
 
+def loop_scratch(asm_text):
+    """{kernel symbol: (blocks inside loops, MFMAs inside loops, scratch loads inside loops, scratch stores inside loops, scratch ops
+    outside loops)} — LLVM marks every block of a loop body with "in Loop:" (the header with "Loop Header").  Since round 5
+    attention's PV slots hold scalar branches (the skipped Vl·P MFMAs), so its MFMA-carrying blocks are short and the
+    per-block rule above no longer sees them all; what matters is this: NO scratch traffic anywhere inside a loop."""
+    out = {}
+    for m in re.finditer(r'^(_Z\w+):[^\n]*\n(.*?)s_endpgm', asm_text, re.S | re.M):
+        in_loop = False
+        nb = nm = sl = ss = outside = 0
+        for l in m.group(2).split('\n'):
+            if re.match(r'^\.LBB', l):
+                in_loop = ("in Loop" in l) or ("Loop Header" in l)
+                nb += in_loop
+            if in_loop:
+                nm += 'v_mfma' in l; sl += 'scratch_load' in l; ss += 'scratch_store' in l
+            else:
+                outside += ('scratch_load' in l) or ('scratch_store' in l)
+        out[m.group(1)] = (nb, nm, sl, ss, outside)
+    return out
+
+
 if __name__ == "__main__":
     res = mfma_blocks(open(sys.argv[1]).read(), int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     for k, rows in res.items():
         print(k[:60], "\n   (block, mfma, scratch_load, scratch_store, lds_dma, vmcnt waits):", rows)
+    for k, v in loop_scratch(open(sys.argv[1]).read()).items():
+        print(k[:60], "\n   (loop blocks, MFMAs in loops, scratch loads / stores in loops, scratch ops outside loops):", v)

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   struct kf_t { i4v_t a, b; };
   constexpr int NG_QK = C8 ? 12 : 8;
   constexpr int NG_PV = VL ? 16 : 8;      // split modes: every V fragment twice, from the Vh and the Vl image
-  constexpr int NSLOT = NG_QK + NG_PV;
+  // (slots of a full sequence: NG_QK + NG_PV; of a Vh-only one NG_QK + NG_PV / 2 — see npv below)
 #ifndef ZK_ATT_LA
 #define ZK_ATT_LA 4
 #endif
@@ -331,10 +331,45 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     vofs[mb] = lds0 + (unsigned)(V_OFF + v_key * 128 + (((4 * mb + v_chunk) ^ v_sw) << 4) + v_byte);
   unsigned ka[4], va[2];      // the same with the ring slots of the iteration added
   auto nreads = [](int g) constexpr { return g >= NG_QK ? 2 : (C8 ? ((g >> 1) < 2 ? 2 : 1) : (SPLIT ? 2 : 1)); };
-  auto reads_after = [nreads](int g) constexpr {
+  static_assert(LA * 2 + 2 <= 15, "lgkmcnt is a 4-bit counter");
+  // ---- the Vl·P pass only where it can matter ----
+  // v's lo plane corrects the fp16 rounding of v (2^-11 relative).  A key whose softmax weight is below 2^-VL_SKIP_LOG2 of the
+  // row's sum adds at most 2^-(11 + VL_SKIP_LOG2) of |v| through it, and keys that small come in crowds whose lo parts
+  // average out (64 of them: 2^-15 of |v|, the size of the fp8 correction residues of the GEMMs).  So a wave runs the Vl·P
+  // MFMAs of a key tile only if SOME row of its 32 has a key in the tile that weighs more than that against the row's sum so
+  // far (skip_vl: a scalar branch around each Vl·P MFMA, mfma_vl below).  Their fragment reads stay: the counted waits of the
+  // slot sequence depend on them, and a second, Vh-only instantiation of the sequence (vlt = false below: built, 2x the loop
+  // code) sent hipcc's register allocation over the edge (256 VGPRs and > 1000 spills against 222 and none).  Measured on the
+  // input-sensitive weight set (CPU emulation of the rule, tools/vl_skip_emul.py): 64 % of the (wave, tile) pairs skip at 2^-5,
+  // logit error 1e-5 against 1.5e-3 for dropping the pass altogether; `wide` 75 %, `heavy` 87 %.
+#ifndef ZK_ATT_VL_SKIP_LOG2
+#define ZK_ATT_VL_SKIP_LOG2 5      // 0 = never skip (every tile runs the full sequence)
+#endif
+  // (not in the layer-0 launches, GEN: on the input-sensitive weight set a perturbation of layer 0 reaches the logits ~15x
+  // amplified, that of any later layer hardly at all; the two layer-0 launches are 1 % of the attention time)
+  constexpr bool VL_SKIP = VL && ZK_ATT_VL_SKIP_LOG2 > 0 && !GEN;
+  constexpr float VL_TAU = VL_SKIP ? 1.0f / (float)(1 << ZK_ATT_VL_SKIP_LOG2) : 0.f;
+  // One Vl·P MFMA behind a SCALAR branch, as ONE asm statement: a C++ `if` around the builtin splits the slot sequence into
+  // ~40 basic blocks per tile, hipcc's allocator then needs 256 registers + spills where the straight-line form takes 222 — and
+  // it spills fragment registers whose ds_read is still in flight (it cannot know the asm reads above are asynchronous:
+  // NaNs).  Inside the asm nothing is visible to the allocator.  Hazards the compiler would have covered: 2 wait states
+  // between a VALU write of P and the MFMA; `last`: the wait states before a VALU instruction (deferred rescale, finalize)
+  // may read the accumulator (8-pass MFMA).
+  auto mfma_vl = [](f16_t& acc, h8_t a, h8_t b, int skip, auto last_c) __attribute__((always_inline)) {
+    const int sk = __builtin_amdgcn_readfirstlane(skip);      // ("s" alone does not move a value the allocator keeps in a VGPR)
+    if constexpr (decltype(last_c)::value)
+      asm volatile("s_cmp_lg_u32 %3, 0\n\ts_cbranch_scc1 .Lzk_vlskip%=\n\ts_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\t"
+                   "s_nop 7\n\ts_nop 7\n\ts_nop 1\n.Lzk_vlskip%=:" : "+v"(acc) : "v"(a), "v"(b), "s"(sk) : "scc");
+    else
+      asm volatile("s_cmp_lg_u32 %3, 0\n\ts_cbranch_scc1 .Lzk_vlskip%=\n\ts_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n"
+                   ".Lzk_vlskip%=:" : "+v"(acc) : "v"(a), "v"(b), "s"(sk) : "scc");
+  };
+  // position p of the early waves' slot order -> group id (the ids keep the full numbering: PV group NG_QK + 2v + img)
+  auto npv = [](bool vlt) constexpr { return (VL && !vlt) ? NG_PV / 2 : NG_PV; };
+  auto seq_g = [](int p, bool vlt) constexpr { return p < NG_QK ? p : NG_QK + ((VL && !vlt) ? 2 * (p - NG_QK) : p - NG_QK); };
+  auto seq_reads_after = [nreads, seq_g](int p, int n_pos, bool vlt) constexpr {
     int n = 0;
-    for (int j = g + 1; j <= g + LA && j < NSLOT; ++j) n += nreads(j);
-    static_assert(LA * 2 + 2 <= 15, "lgkmcnt is a 4-bit counter");
+    for (int j = p + 1; j <= p + LA && j < n_pos; ++j) n += nreads(seq_g(j, vlt));
     return n;
   };
   // (fic: which fragment register set — the position of the group in the wave's slot order modulo LA + 1)
@@ -504,6 +539,12 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
 
   f16_t sA[2], sB[2];
   float mx = 0.f;
+  // (the skip flags are wave-uniform 0 / 1 integers, forced into SGPRs by readfirstlane: mfma_vl compares them with s_cmp)
+  auto all_small = [&](float mxv) __attribute__((always_inline)) {      // no key of the tile weighs more than VL_TAU of the row's sum so far
+    return __builtin_amdgcn_readfirstlane(__all(__builtin_amdgcn_exp2f(mxv) <= VL_TAU * l_run) ? 1 : 0);
+  };
+  int skip_t0 = 0;      // tile 0 needs no Vl·P (possible only when a tabulated state precedes it: l_run > 0)
+  int skip_vl = 0;      // the Vl·P MFMAs of the PV slots that run next are skipped
   if (wave_active) {      // scores of tile 0 (no overlap partner yet)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) ka[ks] = kofs[ks];      // K(0) is in slot 0
@@ -514,6 +555,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     });
     mx = row_max(sA);
     if constexpr (INIT) {      // a reference exists already (the state's): it moves by the deferred-rescale rule, O and l follow
+      if constexpr (VL_SKIP) skip_t0 = all_small(mx);
       if (!__all(mx <= RESCALE_THR)) {
         const float delta = fmaxf(mx, 0.f);
         rescale(sA, delta, __builtin_amdgcn_exp2f(-delta));
@@ -528,15 +570,17 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   int kslot = 0;      // ring slot of the current tile (kt % 3)
   // One key tile.  sc: its scores minus the running max, mx: their row maximum (both from the previous iteration);
   // sn: receives the scores of tile kt+1.  LAST: no next tile; MASKNEXT: tile kt+1 is the last one (masked keys).
-  auto iteration = [&](int kt, f16_t (&sc)[2], f16_t (&sn)[2], auto last_c, auto masknext_c) __attribute__((always_inline)) {
+  auto iteration = [&](int kt, f16_t (&sc)[2], f16_t (&sn)[2], auto last_c, auto masknext_c, auto vlt_c) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_c)::value;
     constexpr bool MASKNEXT = decltype(masknext_c)::value;
+    constexpr bool VLT = decltype(vlt_c)::value;      // with the Vl·P groups (false: this tile's weights are all small, Vh only)
+    constexpr int NPV = npv(VLT), NPOS = NG_QK + NPV;
     constexpr int G0 = LAST ? NG_QK : 0;      // the last tile has PV slots only
     // ring slots: K(t) sits in slot t % 3 (ks0), V(t) in slot t % 3 (vs0)
     const int s0 = kslot, s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;      // t%3, (t+1)%3, (t+2)%3
     // staging of K(t+3) -> slot of K(t) (dead since the previous barrier) and V(t+2) -> slot of V(t-1) = (t+2) % 3: one
     // piece every DMA_EVERY slots, between the MFMAs (a piece holds the issuing wave for ~100 cycles)
-    constexpr int DMA_EVERY = NSLOT / PER_ITER;
+    constexpr int DMA_EVERY = NPOS / PER_ITER;
     auto stage_piece = [&](int pc) __attribute__((always_inline)) {
 #if ZK_ATT_ABL & 8
       if (pc & 1) return;      // (timing probe: half of the staging, wrong results)
@@ -564,31 +608,40 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       }
       float psum = 0.f, mxp = -3.0e38f;
       h8_t pf[2][2];
-      static_for<LA>([&](auto gc) __attribute__((always_inline)) {
-        load_group(std::integral_constant<int, G0 + decltype(gc)::value>{});
+      // (positions p = G0 .. NPOS-1 of the slot order; group id g = seq_g(p); fragment register set p % (LA + 1))
+      static_for<LA>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int p = G0 + decltype(ic)::value;
+        if constexpr (p < NPOS) load_group_at(std::integral_constant<int, seq_g(p, VLT)>{}, std::integral_constant<int, p % (LA + 1)>{});
       });
       if constexpr (LAST) {      // nothing to overlap the exponentials with
 #pragma unroll
         for (int e = 0; e < 32; e += 2) psum = exp_pair(sc, pf, e, psum);
       }
       __builtin_amdgcn_sched_barrier(0);
-      static_for<NSLOT - G0>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int g = G0 + decltype(ic)::value;
-        if constexpr (!ZK_ATT_DMA_TOP && !LAST && g % DMA_EVERY == DMA_EVERY - 1 && g / DMA_EVERY < PER_ITER) stage_piece(g / DMA_EVERY);
-        if constexpr (g + LA < NSLOT) load_group(std::integral_constant<int, g + LA>{});
-        wait_group(std::integral_constant<int, g>{}, std::integral_constant<int, reads_after(g)>{});
+      static_for<NPOS - G0>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int p = G0 + decltype(ic)::value, g = seq_g(p, VLT);
+        using FI = std::integral_constant<int, p % (LA + 1)>;
+        if constexpr (!ZK_ATT_DMA_TOP && !LAST && p % DMA_EVERY == DMA_EVERY - 1 && p / DMA_EVERY < PER_ITER) stage_piece(p / DMA_EVERY);
+        if constexpr (p + LA < NPOS)
+          load_group_at(std::integral_constant<int, seq_g(p + LA, VLT)>{}, std::integral_constant<int, (p + LA) % (LA + 1)>{});
+        wait_group_at(std::integral_constant<int, g>{}, FI{}, std::integral_constant<int, seq_reads_after(p, NPOS, VLT)>{});
         if constexpr (g < NG_QK) {
-          mma_group(std::integral_constant<int, g>{}, sn);
+          mma_group_at(std::integral_constant<int, g>{}, FI{}, sn);
 #pragma unroll
           for (int e = exp_first(g); e < exp_first(g) + exp_count(g); e += 2) psum = exp_pair(sc, pf, e, psum);
         } else {
+          constexpr int pvp = p - NG_QK;      // position among this sequence's PV slots (the row-maximum shares go by it)
           constexpr int pv = g - NG_QK, v = VL ? pv / 2 : pv, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
-          constexpr int EPS = 32 / NG_PV;      // elements of the next tile's row maximum per PV slot
-          oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[g % (LA + 1)].a), pf[kb][sx],
-                                                            oacc[mb], 0, 0, 0);      // (split modes: Vh·P, then Vl·P)
+          constexpr int EPS = 32 / NPV;      // elements of the next tile's row maximum per PV slot
+          // (split modes: Vh·P, then Vl·P — the latter only where it can matter: skip_vl is wave-uniform, a scalar branch around
+          // one MFMA; its fragment reads stay in the sequence, the counted lgkmcnt waits depend on them)
+          if constexpr (VL_SKIP && pv % 2 == 1)
+            mfma_vl(oacc[mb], __builtin_bit_cast(h8_t, fr[FI::value].a), pf[kb][sx], skip_vl, std::bool_constant<pv == NG_PV - 1>{});
+          else
+            oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pf[kb][sx], oacc[mb], 0, 0, 0);
           if constexpr (!LAST) {
 #pragma unroll
-            for (int e = EPS * pv; e < EPS * pv + EPS; ++e) {
+            for (int e = EPS * pvp; e < EPS * pvp + EPS; ++e) {
               constexpr int dummy = 0; (void)dummy;
               const int kbn = e >> 4, r = e & 15;
               if constexpr (MASKNEXT) {
@@ -624,12 +677,14 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   // live anyway), a fourth V ring slot (V(t-1) is read while V(t+2) lands), one more instantiation of the slot sequence.
   h8_t pfr[2][2];      // the late waves' P tile (written in the score half, read in the next interval's PV half)
   // position p of the late waves' slot order -> group
-  auto rot_g = [](int p) constexpr { return p < NG_PV ? NG_QK + p : p - NG_PV; };
-  auto rot_reads_after = [nreads, rot_g](int p, int n_pos) constexpr {
+  // (vlt = false: the Vh groups only, see "the Vl·P pass only where it can matter")
+  auto rot_g = [npv](int p, bool vlt) constexpr { return p < npv(vlt) ? NG_QK + ((VL && !vlt) ? 2 * p : p) : p - npv(vlt); };
+  auto rot_reads_after = [nreads, rot_g](int p, int n_pos, bool vlt) constexpr {
     int n = 0;
-    for (int j = p + 1; j <= p + LA && j < n_pos; ++j) n += nreads(rot_g(j));
+    for (int j = p + 1; j <= p + LA && j < n_pos; ++j) n += nreads(rot_g(j, vlt));
     return n;
   };
+  int skip_late = 0;      // late waves: the Vl·P MFMAs of the tile whose PV half comes next are skipped (wave-uniform)
   // the 32-lane exchange of the row maximum as a VALU swap (ds_bpermute would count in lgkmcnt, in the middle of the slots)
   auto xhalf_max = [](float v) __attribute__((always_inline)) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -638,10 +693,12 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   // One interval of a late wave.  FIRST: interval 0 (score half only: QK(1) ‖ exp(s_0)); FINAL: the part behind the last
   // barrier (PV(NKT-2) ‖ max(s_NKT-1) with the padding keys masked, exp(s_NKT-1), PV(NKT-1)); otherwise interval kt =
   // PV(kt-1) ‖ max(sc = s_kt), [rescale], QK(kt+1) -> sn ‖ exp(sc) -> pfr.
-  auto interval_late = [&](int kt, f16_t (&sc)[2], f16_t (&sn)[2], auto first_c, auto final_c) __attribute__((always_inline)) {
+  auto interval_late = [&](int kt, f16_t (&sc)[2], f16_t (&sn)[2], auto first_c, auto final_c, auto vlt_c) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_c)::value, FINAL = decltype(final_c)::value;
-    constexpr int P0 = FIRST ? NG_PV : 0;                 // first position executed
-    constexpr int P1 = FINAL ? NG_PV : NSLOT;             // one past the last
+    constexpr bool VLT = decltype(vlt_c)::value;          // the PV half of this interval (tile kt-1) with its Vl·P groups
+    constexpr int NPV = npv(VLT), NPOS = NG_QK + NPV;
+    constexpr int P0 = FIRST ? NPV : 0;                   // first position executed
+    constexpr int P1 = FINAL ? NPV : NPOS;                // one past the last
     const int s0 = kslot, s1 = s0 == 2 ? 0 : s0 + 1;      // kt%3, (kt+1)%3
     auto stage_piece = [&](int pc) __attribute__((always_inline)) {
 #if !(ZK_ATT_ABL & 1)
@@ -662,11 +719,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       float psum = 0.f, mxp = -3.0e38f;
       static_for<LA>([&](auto ic) __attribute__((always_inline)) {
         constexpr int p = P0 + decltype(ic)::value;
-        if constexpr (p < P1) load_group_at(std::integral_constant<int, rot_g(p)>{}, std::integral_constant<int, p % (LA + 1)>{});
+        if constexpr (p < P1) load_group_at(std::integral_constant<int, rot_g(p, VLT)>{}, std::integral_constant<int, p % (LA + 1)>{});
       });
       __builtin_amdgcn_sched_barrier(0);
       static_for<P1 - P0>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int p = P0 + decltype(ic)::value, g = rot_g(p);
+        constexpr int p = P0 + decltype(ic)::value, g = rot_g(p, VLT);
         using FI = std::integral_constant<int, p % (LA + 1)>;
         if constexpr (!FINAL) {
           // the interval's staging pieces, spread over its positions (FIRST has only the score half to put them in)
@@ -674,14 +731,17 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
           if constexpr (q % every == every - 1 && q / every < PER_ITER) { if (wave_active) stage_piece(q / every); }
         }
         if constexpr (p + LA < P1)
-          load_group_at(std::integral_constant<int, rot_g(p + LA)>{}, std::integral_constant<int, (p + LA) % (LA + 1)>{});
-        wait_group_at(std::integral_constant<int, g>{}, FI{}, std::integral_constant<int, rot_reads_after(p, P1)>{});
+          load_group_at(std::integral_constant<int, rot_g(p + LA, VLT)>{}, std::integral_constant<int, (p + LA) % (LA + 1)>{});
+        wait_group_at(std::integral_constant<int, g>{}, FI{}, std::integral_constant<int, rot_reads_after(p, P1, VLT)>{});
         if constexpr (g >= NG_QK) {
           constexpr int pv = g - NG_QK, v = VL ? pv / 2 : pv, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
-          constexpr int EPS = 32 / NG_PV;
-          oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], oacc[mb], 0, 0, 0);
+          constexpr int EPS = 32 / NPV;
+          if constexpr (VL_SKIP && pv % 2 == 1)
+            mfma_vl(oacc[mb], __builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], skip_vl, std::bool_constant<pv == NG_PV - 1>{});
+          else
+            oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], oacc[mb], 0, 0, 0);
 #pragma unroll
-          for (int e = EPS * pv; e < EPS * pv + EPS; ++e) {
+          for (int e = EPS * p; e < EPS * p + EPS; ++e) {
             const int kbn = e >> 4, r = e & 15;
             if constexpr (FINAL) {
               const int key = (NKT - 1) * KT + kbn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -689,9 +749,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
             }
             mxp = fmaxf(mxp, sc[kbn][r]);
           }
-          if constexpr (pv == NG_PV - 1) {      // behind the last PV slot: the running maximum moves before the scores start
+          if constexpr (p == NPV - 1) {      // behind the last PV slot: the running maximum moves before the scores start
             __builtin_amdgcn_sched_barrier(0);
             const float mx = xhalf_max(mxp);
+            // does tile kt need its Vl·P groups (next interval's PV half)?  (2^mx against l_run: both relative to m_run)
+            if constexpr (VL_SKIP) skip_late = all_small(mx);
             if (!__all(mx <= RESCALE_THR)) {
               const float delta = fmaxf(mx, 0.f);
               rescale(sc, delta, __builtin_amdgcn_exp2f(-delta));
@@ -710,20 +772,29 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) va[mb] = vofs[mb] + (unsigned)((kt & 3) * VBUF_B);       // V(kt)
         __builtin_amdgcn_sched_barrier(0);
-        static_for<LA>([&](auto ic) __attribute__((always_inline)) {
-          constexpr int p = decltype(ic)::value;
-          load_group_at(std::integral_constant<int, NG_QK + p>{}, std::integral_constant<int, p % (LA + 1)>{});
-        });
-        static_for<NG_PV>([&](auto ic) __attribute__((always_inline)) {
-          constexpr int p = decltype(ic)::value, g = NG_QK + p;
-          using FI = std::integral_constant<int, p % (LA + 1)>;
-          if constexpr (p + LA < NG_PV)
-            load_group_at(std::integral_constant<int, g + LA>{}, std::integral_constant<int, (p + LA) % (LA + 1)>{});
-          wait_group_at(std::integral_constant<int, g>{}, FI{}, std::integral_constant<int, rot_reads_after(p, NG_PV)>{});
-          constexpr int v = VL ? p / 2 : p, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
-          oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], oacc[mb], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        });
+        auto final_pv = [&](auto v2_c) __attribute__((always_inline)) {      // PV(NKT-1), with or without its Vl·P groups
+          constexpr bool V2 = decltype(v2_c)::value;
+          constexpr int NP2 = npv(V2);
+          static_for<LA>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int p = decltype(ic)::value;
+            load_group_at(std::integral_constant<int, rot_g(p, V2)>{}, std::integral_constant<int, p % (LA + 1)>{});
+          });
+          static_for<NP2>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int p = decltype(ic)::value, g = rot_g(p, V2);
+            using FI = std::integral_constant<int, p % (LA + 1)>;
+            if constexpr (p + LA < NP2)
+              load_group_at(std::integral_constant<int, rot_g(p + LA, V2)>{}, std::integral_constant<int, (p + LA) % (LA + 1)>{});
+            wait_group_at(std::integral_constant<int, g>{}, FI{}, std::integral_constant<int, rot_reads_after(p, NP2, V2)>{});
+            constexpr int pv = g - NG_QK, v = VL ? pv / 2 : pv, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
+            if constexpr (VL_SKIP && pv % 2 == 1)
+              mfma_vl(oacc[mb], __builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], skip_vl, std::bool_constant<pv == NG_PV - 1>{});
+            else
+              oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], oacc[mb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        };
+        skip_vl = skip_late;
+        final_pv(std::true_type{});
       }
       l_run += psum;
     }
@@ -744,24 +815,35 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   if ((ZK_ATT_STG_PRIO == 1) == (wave >= NW / 2)) __builtin_amdgcn_s_setprio(1);
 #endif
   if (wave >= NW / 2) {      // (wave-uniform; both branches pass the same NKT-1 barriers)
-    interval_late(0, sA, sB, T{}, F{});
+    // (the PV half of interval kt belongs to tile kt-1: skip_late was decided for it one interval earlier)
+    auto late = [&](int kt, f16_t (&sc)[2], f16_t (&sn)[2], auto first_c, auto final_c) __attribute__((always_inline)) {
+      skip_vl = skip_late;      // (decided for tile kt-1 one interval earlier; interval_late sets skip_late for tile kt)
+      interval_late(kt, sc, sn, first_c, final_c, T{});
+    };
+    skip_late = skip_t0;
+    interval_late(0, sA, sB, T{}, F{}, T{});      // (no PV half)
     for (int kt = 1; kt < NKT - 2; kt += 2) {
-      interval_late(kt, sB, sA, F{}, F{});
-      interval_late(kt + 1, sA, sB, F{}, F{});
+      late(kt, sB, sA, F{}, F{});
+      late(kt + 1, sA, sB, F{}, F{});
     }
     static_assert((NKT - 3) % 2 == 0, "the late waves' loop ends on interval NKT-3 with the roles (sA, sB)");
-    interval_late(NKT - 2, sB, sA, F{}, F{});
-    interval_late(NKT - 1, sA, sB, F{}, T{});
+    late(NKT - 2, sB, sA, F{}, F{});
+    late(NKT - 1, sA, sB, F{}, T{});
   } else
 #endif
   {
+  // (mx = row maximum of tile kt against the running reference, l_run = the sum over the tiles before it: both known here)
+  auto early = [&](int kt, f16_t (&sc)[2], f16_t (&sn)[2], auto last_c, auto masknext_c) __attribute__((always_inline)) {
+    if constexpr (VL_SKIP) { if (wave_active) skip_vl = kt == 0 ? skip_t0 : all_small(mx); }
+    iteration(kt, sc, sn, last_c, masknext_c, T{});
+  };
   for (int kt = 0; kt < NKT - 3; kt += 2) {
-    iteration(kt, sA, sB, F{}, F{});
-    iteration(kt + 1, sB, sA, F{}, F{});
+    early(kt, sA, sB, F{}, F{});
+    early(kt + 1, sB, sA, F{}, F{});
   }
-  iteration(NKT - 3, sA, sB, F{}, F{});
-  iteration(NKT - 2, sB, sA, F{}, T{});
-  iteration(NKT - 1, sA, sB, T{}, F{});
+  early(NKT - 3, sA, sB, F{}, F{});
+  early(NKT - 2, sB, sA, F{}, T{});
+  early(NKT - 1, sA, sB, T{}, F{});
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the surplus pieces of the last iterations)
