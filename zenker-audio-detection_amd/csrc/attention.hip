@@ -520,7 +520,13 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   // the ROUNDED values, not the fp32 ones.  O / l is then an exactly normalised average with
   // weights fp16(p): a weight's rounding error enters as δ·p·(v − O) instead of δ·p·v, which vanishes for the sharply
   // peaked rows where one key carries the sum (measured on the input-sensitive weight set: logit error -28 %).
-  auto exp_pair = [&](f16_t (&sc)[2], h8_t (&pf)[2][2], int e, float acc) __attribute__((always_inline)) {
+  // Layer-0 launches (GEN): the softmax weights go to the P·V MFMAs as (hi, lo) fp16 PAIRS — P·V = Ph·Vh + Pl·Vh + Ph·Vl, the
+  // row sum over ph + pl.  On the input-sensitive weight set the fp16 rounding of P in layer 0 alone is the largest term left
+  // once that layer's GEMMs run f16x3 (1.5e-4 rms of a logit, 70 % of what P's rounding costs over all twelve layers:
+  // tools/sens_budget.py PER_LAYER), and the layer-0 launches are 1 % of the attention time: 8 more MFMAs per tile there, no
+  // fragment read more (Pl·Vh rides in the Vh slot).
+  constexpr bool PSPLIT = GEN && SPLIT;
+  auto exp_pair = [&](f16_t (&sc)[2], h8_t (&pf)[2][2], h8_t (&pl)[2][2], int e, float acc) __attribute__((always_inline)) {
 #if ZK_ATT_ABL & 4
     const float p0 = sc[e >> 4][e & 15], p1 = sc[e >> 4][(e & 15) + 1];
 #else
@@ -534,6 +540,16 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     float r;
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pr), "v"(acc));
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(pr), "v"(r));
+    if constexpr (PSPLIT) {      // lo = fp16(p - fp16(p)) by one v_fma_mixlo / _mixhi each (zk_lo4's form), summed into l as well
+      unsigned d;
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pr), "v"(p0));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(pr), "v"(p1));
+      const h2_t lo = __builtin_bit_cast(h2_t, d);
+      pl[e >> 4][(e & 15) >> 3][e & 7] = lo[0];
+      pl[e >> 4][(e & 15) >> 3][(e & 7) + 1] = lo[1];
+      asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(lo), "v"(acc));
+      asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(lo), "v"(r));
+    }
     return acc;
   };
 
@@ -607,7 +623,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
         rescale(sc, delta, __builtin_amdgcn_exp2f(-delta));
       }
       float psum = 0.f, mxp = -3.0e38f;
-      h8_t pf[2][2];
+      h8_t pf[2][2], pfl[PSPLIT ? 2 : 1][PSPLIT ? 2 : 1];
+      auto& pfl_ = reinterpret_cast<h8_t (&)[2][2]>(*(PSPLIT ? &pfl[0][0] : &pf[0][0]));      // (unused without PSPLIT)
       // (positions p = G0 .. NPOS-1 of the slot order; group id g = seq_g(p); fragment register set p % (LA + 1))
       static_for<LA>([&](auto ic) __attribute__((always_inline)) {
         constexpr int p = G0 + decltype(ic)::value;
@@ -615,7 +632,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       });
       if constexpr (LAST) {      // nothing to overlap the exponentials with
 #pragma unroll
-        for (int e = 0; e < 32; e += 2) psum = exp_pair(sc, pf, e, psum);
+        for (int e = 0; e < 32; e += 2) psum = exp_pair(sc, pf, pfl_, e, psum);
       }
       __builtin_amdgcn_sched_barrier(0);
       static_for<NPOS - G0>([&](auto ic) __attribute__((always_inline)) {
@@ -628,7 +645,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
         if constexpr (g < NG_QK) {
           mma_group_at(std::integral_constant<int, g>{}, FI{}, sn);
 #pragma unroll
-          for (int e = exp_first(g); e < exp_first(g) + exp_count(g); e += 2) psum = exp_pair(sc, pf, e, psum);
+          for (int e = exp_first(g); e < exp_first(g) + exp_count(g); e += 2) psum = exp_pair(sc, pf, pfl_, e, psum);
         } else {
           constexpr int pvp = p - NG_QK;      // position among this sequence's PV slots (the row-maximum shares go by it)
           constexpr int pv = g - NG_QK, v = VL ? pv / 2 : pv, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
@@ -637,8 +654,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
           // one MFMA; its fragment reads stay in the sequence, the counted lgkmcnt waits depend on them)
           if constexpr (VL_SKIP && pv % 2 == 1)
             mfma_vl(oacc[mb], __builtin_bit_cast(h8_t, fr[FI::value].a), pf[kb][sx], skip_vl, std::bool_constant<pv == NG_PV - 1>{});
-          else
+          else {
             oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pf[kb][sx], oacc[mb], 0, 0, 0);
+            if constexpr (PSPLIT && pv % 2 == 0)      // Pl·Vh on the Vh fragment just used
+              oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfl_[kb][sx], oacc[mb], 0, 0, 0);
+          }
           if constexpr (!LAST) {
 #pragma unroll
             for (int e = EPS * pvp; e < EPS * pvp + EPS; ++e) {
@@ -676,6 +696,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   // other's exp-heavy score slots instead of both waves in the same phase.  Costs: P(t-1) lives across the barrier (it is
   // live anyway), a fourth V ring slot (V(t-1) is read while V(t+2) lands), one more instantiation of the slot sequence.
   h8_t pfr[2][2];      // the late waves' P tile (written in the score half, read in the next interval's PV half)
+  h8_t pfrl[PSPLIT ? 2 : 1][PSPLIT ? 2 : 1];      // ... and its lo half (PSPLIT)
+  auto& pfrl_ = reinterpret_cast<h8_t (&)[2][2]>(*(PSPLIT ? &pfrl[0][0] : &pfr[0][0]));
   // position p of the late waves' slot order -> group
   // (vlt = false: the Vh groups only, see "the Vl·P pass only where it can matter")
   auto rot_g = [npv](int p, bool vlt) constexpr { return p < npv(vlt) ? NG_QK + ((VL && !vlt) ? 2 * p : p) : p - npv(vlt); };
@@ -738,8 +760,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
           constexpr int EPS = 32 / NPV;
           if constexpr (VL_SKIP && pv % 2 == 1)
             mfma_vl(oacc[mb], __builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], skip_vl, std::bool_constant<pv == NG_PV - 1>{});
-          else
+          else {
             oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], oacc[mb], 0, 0, 0);
+            if constexpr (PSPLIT && pv % 2 == 0)
+              oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfrl_[kb][sx], oacc[mb], 0, 0, 0);
+          }
 #pragma unroll
           for (int e = EPS * p; e < EPS * p + EPS; ++e) {
             const int kbn = e >> 4, r = e & 15;
@@ -762,13 +787,13 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
         } else {
           mma_group_at(std::integral_constant<int, g>{}, FI{}, sn);
 #pragma unroll
-          for (int e = exp_first(g); e < exp_first(g) + exp_count(g); e += 2) psum = exp_pair(sc, pfr, e, psum);
+          for (int e = exp_first(g); e < exp_first(g) + exp_count(g); e += 2) psum = exp_pair(sc, pfr, pfrl_, e, psum);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
       if constexpr (FINAL) {      // exp(s_NKT-1) with nothing beside it, then PV(NKT-1)
 #pragma unroll
-        for (int e = 0; e < 32; e += 2) psum = exp_pair(sc, pfr, e, psum);
+        for (int e = 0; e < 32; e += 2) psum = exp_pair(sc, pfr, pfrl_, e, psum);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) va[mb] = vofs[mb] + (unsigned)((kt & 3) * VBUF_B);       // V(kt)
         __builtin_amdgcn_sched_barrier(0);
@@ -788,8 +813,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
             constexpr int pv = g - NG_QK, v = VL ? pv / 2 : pv, kb = v / 4, sx = (v / 2) % 2, mb = v % 2;
             if constexpr (VL_SKIP && pv % 2 == 1)
               mfma_vl(oacc[mb], __builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], skip_vl, std::bool_constant<pv == NG_PV - 1>{});
-            else
+            else {
               oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfr[kb][sx], oacc[mb], 0, 0, 0);
+              if constexpr (PSPLIT && pv % 2 == 0)
+                oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fr[FI::value].a), pfrl_[kb][sx], oacc[mb], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
           });
         };

@@ -83,7 +83,7 @@ struct LayerW {
 // kernel group in the 3-pass ZK_F16X3 arithmetic, a clear one in ZK_F16C8 (chosen on the input-sensitive
 // weight set so that a configs[3]-sized recording keeps >= 20 % of the 1e-3 logit tolerance)
 #ifndef ZK_MIX_X3_MASK
-#define ZK_MIX_X3_MASK 0x37ull      // layer 0: QKV, QK^T, O; layer 1: QKV, QK^T (zkast/lib.py: MIX_X3_GROUPS)
+#define ZK_MIX_X3_MASK 0x3ull      // layer 0: QKV, QK^T (zkast/lib.py: MIX_X3_GROUPS)
 #endif
 struct LayerMode { int qkv, att, o, mlp; };
 // attention reads k's lo plane as c8 byte pairs only when the ZK_F16C8 QKV epilogue wrote them, and any lo plane only if

@@ -26,7 +26,7 @@ EPI_STORE, EPI_GELU, EPI_RESID, EPI_PATCH = 0, 1, 2, 3
 TEST_TILED_IN, TEST_TILED_OUT, TEST_POISON_PAD, TEST_SHORT_X = 0x100, 0x200, 0x400, 0x800      # include/zkast.h: ZK_TEST_*
 # the kernel groups ZK_F16MIX runs as ZK_F16X3 (everything else ZK_F16C8), {layer: groups}: ZK_MIX_X3_MASK of csrc/zkast.hip
 LAYER_GROUPS = ("qkv", "att", "o", "mlp")      # fused QKV GEMM, QK^T of attention, O projection, MLP (FC1 + FC2)
-MIX_X3_GROUPS = {0: ("qkv", "att", "o"), 1: ("qkv", "att")}
+MIX_X3_GROUPS = {0: ("qkv", "att")}
 
 
 def mix_layer_modes(x3_groups=None, n_layers: int = 12) -> list:
