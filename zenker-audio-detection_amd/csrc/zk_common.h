@@ -34,6 +34,7 @@ typedef short s4v_t __attribute__((__vector_size__(4 * sizeof(short))));
 #define ZK_FRAME_HOP 160
 #define ZK_FFT 512
 #define ZK_NBINS 257
+#define ZK_MEL_BAND_MAX 1024   // LDS slots for the mel bank's band (sum over filters of mel_hi - mel_lo; 504 for the AST bank)
 
 // activation planes: a tensor is stored as one (hi) or two (hi, lo) 16-bit planes.
 //   lo_fmt ZK_LO_F16: lo = fp16(x - hi), x ~= hi + lo                      (ZK_F16X3 GEMMs, split QK^T)

@@ -867,6 +867,11 @@ int zk_create(int device_id, zk_ctx** out) {
   std::vector<double> hann, tw, mel;
   std::vector<int32_t> lo, hi;
   build_tables(hann, tw, mel, lo, hi);
+  {
+    int band = 0;
+    for (int m = 0; m < ZK_NMEL; ++m) band += hi[m] - lo[m];
+    if (band > ZK_MEL_BAND_MAX) { zk_destroy(c); return fail(nullptr, ZK_E_STATE, "mel band of %d entries exceeds the log-mel kernel's LDS table (%d)", band, ZK_MEL_BAND_MAX); }
+  }
   int rc = upload(c, hann, &c->d_hann);
   if (!rc) rc = upload(c, tw, &c->d_tw);
   if (!rc) rc = upload(c, mel, &c->d_mel);
