@@ -42,8 +42,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_WINDOW_STAGE = 261.03e9          # dense AST forward at S=1214
 PEAK_F16_DENSE = 2.5e15                   # MI355X_MICROARCH.md: BF16/FP16 MFMA dense peak
-TRAFFIC_FILE = "r04_pmc_traffic.json"      # rocprofv3 --pmc passes of this round (tools/pmc_traffic.py)
-CLOCK_FILE = "r04_gemm_clock.json"         # in-kernel s_memtime / s_memrealtime pair of a stamp build (tools/gemm_stamps.py)
+TRAFFIC_FILE = "r05_pmc_traffic.json"      # rocprofv3 --pmc passes of this round (tools/pmc_traffic.py)
+CLOCK_FILE = "r05_gemm_clock.json"         # in-kernel s_memtime / s_memrealtime pair of a stamp build (tools/gemm_stamps.py)
 # matrix-pipe passes per algorithmic FLOP of each compute mode: f16c8 = one fp16 pass + one fp8 pass of
 # K' = 2K bytes at twice the rate = 2 fp16-pass-equivalents; f16x3 = 3 fp16 passes.  Attention, per 64-key tile and wave:
 # a single pass is 16 x 32x32x16 MFMAs = 512 matrix-pipe cycles; f16c8 runs QK^T as 8 fp16 + 4 fp8 32x32x64 (512 cycles) and

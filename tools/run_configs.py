@@ -30,8 +30,11 @@ def main():
     ap.add_argument("--config", type=int, required=True, choices=[3, 4])
     ap.add_argument("--patients", type=int, default=64)
     ap.add_argument("--minutes", type=float, default=None, help="recording length (default 30 for config 3, 5 per file for config 4)")
-    ap.add_argument("--mode", default="f16c8")
+    ap.add_argument("--mode", default=None, help="compute mode (default: zkast.lib.DEFAULT_COMPUTE_MODE)")
     args = ap.parse_args()
+    if args.mode is None:
+        from zkast import lib as _zl
+        args.mode = _zl.DEFAULT_COMPUTE_MODE
     # one JSON line on stdout: gloo / RCCL print banners there, so fd 1 goes to stderr and the line to the saved descriptor
     sys.stdout.flush()
     real_stdout = os.dup(1)
