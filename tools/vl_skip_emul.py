@@ -1,5 +1,8 @@
+"""CPU emulation (torch fp32) of attention's "Vl·P only where it can matter" rule: for thresholds 2^-k, the share of the (wave, key
+tile) pairs whose Vl·P MFMAs the rule skips in every layer, and the largest logit change against always running the pass
+(profiles/r05_attention_vl_skip_ab.txt).  usage: python tools/vl_skip_emul.py <weight set> <seed>      e.g.  sens 31"""
 import os, sys, numpy as np, torch
-ROOT='/root/repo'; sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+'/zenker-audio-detection_amd')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'zenker-audio-detection_amd'))
 from oracle import ast_oracle as orc, ast_torch_cpu as tcpu
 from zkast import synth
 F=torch.nn.functional

@@ -623,8 +623,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
         rescale(sc, delta, __builtin_amdgcn_exp2f(-delta));
       }
       float psum = 0.f, mxp = -3.0e38f;
-      h8_t pf[2][2], pfl[PSPLIT ? 2 : 1][PSPLIT ? 2 : 1];
-      auto& pfl_ = reinterpret_cast<h8_t (&)[2][2]>(*(PSPLIT ? &pfl[0][0] : &pf[0][0]));      // (unused without PSPLIT)
+      h8_t pf[2][2], pfl_[2][2];      // (pfl_: the lo halves of the weights, PSPLIT only — otherwise never touched and gone after optimisation)
       // (positions p = G0 .. NPOS-1 of the slot order; group id g = seq_g(p); fragment register set p % (LA + 1))
       static_for<LA>([&](auto ic) __attribute__((always_inline)) {
         constexpr int p = G0 + decltype(ic)::value;
@@ -696,8 +695,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
   // other's exp-heavy score slots instead of both waves in the same phase.  Costs: P(t-1) lives across the barrier (it is
   // live anyway), a fourth V ring slot (V(t-1) is read while V(t+2) lands), one more instantiation of the slot sequence.
   h8_t pfr[2][2];      // the late waves' P tile (written in the score half, read in the next interval's PV half)
-  h8_t pfrl[PSPLIT ? 2 : 1][PSPLIT ? 2 : 1];      // ... and its lo half (PSPLIT)
-  auto& pfrl_ = reinterpret_cast<h8_t (&)[2][2]>(*(PSPLIT ? &pfrl[0][0] : &pfr[0][0]));
+  h8_t pfrl_[2][2];    // ... and its lo half (PSPLIT only)
   // position p of the late waves' slot order -> group
   // (vlt = false: the Vh groups only, see "the Vl·P pass only where it can matter")
   auto rot_g = [npv](int p, bool vlt) constexpr { return p < npv(vlt) ? NG_QK + ((VL && !vlt) ? 2 * p : p) : p - npv(vlt); };
