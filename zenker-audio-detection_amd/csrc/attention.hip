@@ -88,6 +88,11 @@ constexpr int NW = ZK_ATT_NW;
 #ifndef ZK_ATT_STAGGER
 #define ZK_ATT_STAGGER 1      // waves 4-7 run half an iteration behind their SIMD partners (see "staggered waves" below); 0 = lockstep form
 #endif
+#ifndef ZK_ATT_PERSIST_L0
+#define ZK_ATT_PERSIST_L0 0     // probe: 2 = the layer-0 constant-query launch (att_ext, VAR 2) in the persistent form.  Its items are three
+                                // key tiles long (launch + prologue + store tail are most of an item), but inside the item loop hipcc
+                                // needs 256 VGPRs + 120-135 spilled registers for it (230 and none outside): not shipped
+#endif
 #ifndef ZK_ATT_PERSIST
 #define ZK_ATT_PERSIST 0      // probe (measured +1.0 % in f16c8, -0.5 % in f16x3: profiles/r03_attention_stagger_ab.txt): 1 / 2 = one workgroup per
                               // CU walks its XCD's share of the (window, head, query tile) items (2: q loads behind the stores, no spills)
@@ -102,7 +107,9 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
                                                         half_t* __restrict__ o_lo, int n_windows, int q_tiles, int lo_fmt, int row_limit, int rev,
                                                         int o_tiled, const att_ext x) {
   constexpr bool GEN = VAR != 0, INIT = VAR == 2, DUMP = VAR == 3;
-  static_assert(!GEN || !ZK_ATT_PERSIST, "the generalised launches exist in the non-persistent form only");
+  // persistent form (one workgroup per CU walks its XCD's share of the items): probe switches for the ordinary launch
+  // (ZK_ATT_PERSIST) and for the layer-0 constant-query launch (VAR 2, ZK_ATT_PERSIST_L0)
+  constexpr int PERS = VAR == 2 ? ZK_ATT_PERSIST_L0 : (GEN ? 0 : ZK_ATT_PERSIST);
   constexpr bool SPLIT = (NSPLIT >= 2);
   constexpr bool C8 = (NSPLIT == 2);
   // LDS images of one 64-key tile: K: Kh, [Kl | Kc8]; V: Vh, [Vl].  Vl = fp16(v - fp16(v)), the lo plane the QKV epilogue
@@ -137,26 +144,26 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     tok0 = (size_t)(wg / (q_tiles * ZK_HEADS)) * S_;
     if constexpr (GEN) brow0 = (size_t)(wg / (q_tiles * ZK_HEADS)) * x.b_rows;
   };
-#if ZK_ATT_PERSIST
   // Persistent form: the workgroup walks items j, j + per, j + 2 per, ... of its XCD's share (at any moment the CUs of an
   // XCD work on neighbouring items, as the hardware's own dispatch order had it).  The NEXT item's q loads and K/V
   // prologue pieces are issued in front of THIS item's output stores, so the memory round trip of a prologue, the store
   // tail and the workgroup launch no longer sit exposed on a CU that holds only this one workgroup.
-  const int x_q = nwg >> 3, x_r = nwg & 7, x_id = (int)blockIdx.x & 7, x_per = (int)gridDim.x >> 3;
-  const int x_start = x_id < x_r ? x_id * (x_q + 1) : x_r * (x_q + 1) + (x_id - x_r) * x_q;
-  const int x_count = x_q + (x_id < x_r ? 1 : 0);
-  int it_idx = (int)blockIdx.x >> 3;
-  if (it_idx >= x_count) return;
+  int it_idx = 0, x_count = 0, x_per = 0, x_start = 0;
   auto item_wg = [&](int idx) __attribute__((always_inline)) { return x_start + (rev ? x_count - 1 - idx : idx); };      // rev: last item first
-  set_item(item_wg(it_idx));
-#else
-  {
+  if constexpr (PERS) {
+    const int x_q = nwg >> 3, x_r = nwg & 7, x_id = (int)blockIdx.x & 7;
+    x_per = (int)gridDim.x >> 3;
+    x_start = x_id < x_r ? x_id * (x_q + 1) : x_r * (x_q + 1) + (x_id - x_r) * x_q;
+    x_count = x_q + (x_id < x_r ? 1 : 0);
+    it_idx = (int)blockIdx.x >> 3;
+    if (it_idx >= x_count) return;
+    set_item(item_wg(it_idx));
+  } else {
     const int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;      // rev: last window first
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     set_item((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx);
   }
-#endif
 
   // ---- Q fragments (B operand: lane holds Q[q = lane&31][d = 16ks + 8*half + j]) ----
   h8_t qh[4], ql[(SPLIT && !C8) ? 4 : 1];      // ql: q's fp16 lo fragments, kept only where the 3-term split reads them later
@@ -904,20 +911,21 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
     }
   }
   const size_t orow0 = (tok0 + (size_t)row_base) * ZK_HIDDEN + head * ZK_HEAD_DIM;
-#if ZK_ATT_PERSIST
-  // next item: its q loads and K/V prologue pieces go out in front of this item's stores.  The barrier: every wave is past
-  // its last fragment read, the rings may be overwritten.
-  it_idx += x_per;
-  const bool more = it_idx < x_count;
-  __builtin_amdgcn_s_barrier();
-  if (more) {
-    set_item(item_wg(it_idx));
-#if ZK_ATT_PERSIST == 1
-    q_issue();
-#endif
-    kv_prologue();
+  const size_t tok0_c = tok0;      // (the item whose rows are about to be stored: set_item below moves on to the next one)
+  const int head_c = head;
+  bool more = false;
+  if constexpr (PERS) {
+    // next item: its q loads and K/V prologue pieces go out in front of this item's stores.  The barrier: every wave is past
+    // its last fragment read, the rings may be overwritten.
+    it_idx += x_per;
+    more = it_idx < x_count;
+    __builtin_amdgcn_s_barrier();
+    if (more) {
+      set_item(item_wg(it_idx));
+      if constexpr (PERS == 1) q_issue();
+      kv_prologue();
+    }
   }
-#endif
   auto flush = [&](half_t* plane) __attribute__((always_inline)) {      // staged rows -> global, 4 x (8 rows x 128 B)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -933,12 +941,12 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       if constexpr (GEN) {      // output row -> token of the window (att_out_token)
         const int row = row_base + r;
         valid = row >= x.q_lo && row < n_q;
-        const size_t trow = tok0 + (size_t)att_out_token(valid ? row : x.q_lo, x.out_map, x.q_lo, x.tr);
-        oo = o_tiled ? zk_tiled_off((int)trow, head * ZK_HEAD_DIM + rd_ch * 8, ZK_HIDDEN)
-                     : trow * ZK_HIDDEN + head * ZK_HEAD_DIM + rd_ch * 8;
+        const size_t trow = tok0_c + (size_t)att_out_token(valid ? row : x.q_lo, x.out_map, x.q_lo, x.tr);
+        oo = o_tiled ? zk_tiled_off((int)trow, head_c * ZK_HEAD_DIM + rd_ch * 8, ZK_HIDDEN)
+                     : trow * ZK_HIDDEN + head_c * ZK_HEAD_DIM + rd_ch * 8;
       } else {
         valid = row_base + r < S_;
-        oo = o_tiled ? zk_tiled_off((int)(tok0 + row_base + r), head * ZK_HEAD_DIM + rd_ch * 8, ZK_HIDDEN)
+        oo = o_tiled ? zk_tiled_off((int)(tok0_c + row_base + r), head_c * ZK_HEAD_DIM + rd_ch * 8, ZK_HIDDEN)
                      : orow0 + (size_t)r * ZK_HIDDEN + rd_ch * 8;
       }
       if (valid) *(h8_t*)(plane + oo) = v;
@@ -972,14 +980,12 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const half_t* __rest
       flush(o_lo);
     }
   }
-#if ZK_ATT_PERSIST
-  if (!more) break;
-#if ZK_ATT_PERSIST == 2      // (q loads behind the stores: their 32 registers do not overlap the output path's)
-  q_issue();
-#endif
-#else
-  break;
-#endif
+  if constexpr (PERS) {
+    if (!more) break;
+    if constexpr (PERS == 2) q_issue();      // (q loads behind the stores: their 32 registers do not overlap the output path's)
+  } else {
+    break;
+  }
   }      // item loop
 }
 
@@ -1043,11 +1049,14 @@ void zk_launch_attention_l0(int what, zk_planes ctab, float* state, zk_planes ta
   constexpr int NIMG_SPLIT = 4;
 #endif
   constexpr int STG_B = NW * 32 * 144, LDS = (3 * 2 + NVS * (NIMG_SPLIT - 2)) * TILE_B + STG_B;
+  // (probe ZK_ATT_PERSIST_L0: the constant-query launch persistent — one workgroup per CU (LDS), a multiple of the 8 XCDs)
+  const bool pers = what == ZK_L0_ATT_CONST && ZK_ATT_PERSIST_L0 != 0;
+  const int pgrid = pers ? (grid < 256 ? ((grid + 7) / 8) * 8 : 256) : grid;
   auto go = [&](auto kernel) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * NW), LDS, s, tail.hi, tail.lo, out.hi, out.lo, nw, wg_tiles, out.lo_fmt, nq, 0, out.tiled, x);
+    hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(64 * NW), LDS, s, tail.hi, tail.lo, out.hi, out.lo, nw, wg_tiles, out.lo_fmt, nq, 0, out.tiled, x);
   };
-#if !ZK_ATT_PERSIST
+  {
   if (nsplit == 2) {
     if (what == ZK_L0_ATT_DUMP) go(attention_kernel<2, 17, 3>);
     else if (what == ZK_L0_ATT_CONST) go(attention_kernel<2, 3, 2>);
@@ -1057,5 +1066,5 @@ void zk_launch_attention_l0(int what, zk_planes ctab, float* state, zk_planes ta
     else if (what == ZK_L0_ATT_CONST) go(attention_kernel<3, 3, 2>);
     else go(attention_kernel<3, NKT_FULL, 1>);
   }
-#endif
+  }
 }
