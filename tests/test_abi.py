@@ -127,3 +127,23 @@ def test_hip_runtime_override_wins_or_fails_loudly(handle):
                         "try:\n    lib.load_library()\n    print('LOADED')\n"
                         "except lib.ZkError as e:\n    print('ZKERROR', e)\n", {"ZKAST_HIP_LIB": sysrt})
             assert "ZKERROR" in r.stdout and "already mapped" in r.stdout, (r.stdout, r.stderr[-2000:])
+
+
+def test_default_mix_assignment_is_stated_once():
+    """ZK_F16MIX's default assignment lives in csrc/zkast.hip (ZK_MIX_X3_MASK: one nibble per layer — QKV GEMM, QK^T, O projection,
+    MLP) and is mirrored by zkast.lib.MIX_X3_GROUPS (what bench.py and the docs print): the two must say the same."""
+    src = open(os.path.join(ROOT, "zenker-audio-detection_amd", "csrc", "zkast.hip")).read()
+    mask = int(re.search(r"#define ZK_MIX_X3_MASK (0x[0-9a-fA-F]+)ull", src).group(1), 16)
+    want = {}
+    for layer in range(12):
+        g = (mask >> (4 * layer)) & 15
+        if g:
+            want[layer] = tuple(name for bit, name in enumerate(lib.LAYER_GROUPS) if g >> bit & 1)
+    assert want == {k: tuple(v) for k, v in lib.MIX_X3_GROUPS.items()}
+    modes = lib.mix_layer_modes()
+    assert len(modes) == 12 and all(len(m) == 4 for m in modes)
+    assert modes[0] == ("f16x3", "f16x3", "f16c8", "f16c8") and all(m == ("f16c8",) * 4 for m in modes[1:])
+    assert lib.mix_layer_modes({3: ("mlp",)})[3] == ("f16c8", "f16c8", "f16c8", "f16x3")
+    assert lib.DEFAULT_COMPUTE_MODE in lib.COMPUTE_MODES and lib.COMPUTE_MODES["f16mix"] == lib.ZK_F16MIX == 4
+    hdr = open(os.path.join(ROOT, "include", "zkast.h")).read()
+    assert re.search(r"ZK_F16MIX\s*=\s*4", hdr)
