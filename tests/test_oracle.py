@@ -222,6 +222,19 @@ def test_resample_restatement_properties():
     ref = np.sin(2 * np.pi * 1000.0 * np.arange(16000) / 16000.0)
     assert np.abs(y[200:-200] - ref[200:-200]).max() < 5e-3
     assert orc.resample_sinc_hann(np.zeros(44101, np.float32), 44100, 16000).shape[0] == int(np.ceil(160 * 44101 / 441))
+    # against an INDEPENDENT resampler (scipy's polyphase Kaiser design — SURVEY 8c: the only outside check possible here): on a
+    # signal band-limited well below the new Nyquist frequency the two must agree; a tone above it must be gone
+    from scipy import signal
+    rng = np.random.default_rng(3)
+    spec = np.zeros(24001, complex)
+    spec[50:5000] = rng.normal(size=4950) + 1j * rng.normal(size=4950)      # 50 Hz .. 5 kHz at one bin per Hz
+    x = np.fft.irfft(spec, 48000)
+    x = (x / np.abs(x).max() * 0.5).astype(np.float32)
+    y = orc.resample_sinc_hann(x, 48000, 16000)
+    z = signal.resample_poly(x.astype(np.float64), 1, 3)
+    assert np.abs(y[300:-300] - z[300:-300]).max() < 5e-3 * np.abs(z).max()
+    tone = np.sin(2 * np.pi * 12000.0 * t).astype(np.float32)      # aliases to 4 kHz unless the low-pass removes it
+    assert np.abs(orc.resample_sinc_hann(tone, 48000, 16000)[300:-300]).max() < 0.02
 
 
 def test_fp8_e4m3_encoder_matches_torch_float8():
