@@ -99,6 +99,14 @@ def test_rccl_allgather_through_the_c_abi_world_of_one():
         ctx.allgather_logits(xd, 450, 2, od)                       # device -> device on the context's stream
         assert np.array_equal(od.cpu().numpy()[0], x)
         assert ctx.allgather_bytes(b"patient 006: ok") == [b"patient 006: ok"] and ctx.allgather_bytes(b"") == [b""]
+        # the "allgather" profile class (bench.py's multi_gpu.per_rank[].allgather_ms_per_step): HIP events around ncclAllGather
+        # of the LOGIT gathers on the context's stream; the byte gathers (barriers of the host code) are not counted
+        ctx.prof_begin()
+        ctx.allgather_logits(x, 450, 2, out)
+        ctx.allgather_logits(xd, 450, 2, od)
+        ctx.allgather_bytes(b"barrier")
+        ms, calls, _ = ctx.prof_end()["allgather"]
+        assert calls == 2 and 0.0 < ms < 50.0
         with pytest.raises(lib.ZkError):
             ctx.comm_init(0, 1, None)                              # a context holds one communicator
         ctx.comm_destroy()
