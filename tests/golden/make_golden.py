@@ -119,7 +119,8 @@ def _fx_chunk(args):
     return fx(list(wins), sampling_rate=16000, return_tensors="np")["input_values"]
 
 
-def make_sens_tail(n=SENS_TAIL_N, rec_seed=SENS_TAIL_REC_SEED, procs=6, threads=6):
+def make_sens_tail(n=SENS_TAIL_N, rec_seed=SENS_TAIL_REC_SEED, procs=6, threads=6, weight_set="sens", seeds=(31, 33), out_name="sens_tail.npz",
+                   gate=True):
     """F7: ONE configs[3]-sized recording (30 min at 16 kHz -> 3 599 windows of 1 s / 0.5 s hop, the count the reference
     loop pushes through both stages per file, src/test_long_audio_windows_2stage.py:301-328) through the REAL
     `ASTFeatureExtractor` + `ASTForAudioClassification` on the input-sensitive `sens` weight set (seeds 31 / 33, the two
@@ -135,14 +136,14 @@ def make_sens_tail(n=SENS_TAIL_N, rec_seed=SENS_TAIL_REC_SEED, procs=6, threads=
     assert len(wins) == n and all(len(w) == 16000 for w in wins)
     torch.set_num_threads(threads)
     pool = mp.get_context("spawn").Pool(procs)      # spawn: the extractor pads with torch operators, which a fork of a threaded parent deadlocks
-    part = os.path.join("/tmp", f"sens_tail_{rec_seed}_{n}.partial.npz")
+    part = os.path.join("/tmp", f"{weight_set}_tail_{rec_seed}_{n}.partial.npz")
     done = dict(np.load(part)) if os.path.exists(part) else {}
 
     def run_stage(tag, seed, mean, std, sel):
         key = f"{tag}_logits"
         if key in done and len(done[key]) == len(sel):
             return done[key]
-        m = hf_model(seed, "sens")
+        m = hf_model(seed, weight_set)
         out = np.zeros((len(sel), 2), np.float32)
         t0 = time.time()
         bs = 64 * procs
@@ -160,22 +161,29 @@ def make_sens_tail(n=SENS_TAIL_N, rec_seed=SENS_TAIL_REC_SEED, procs=6, threads=
         np.savez(part, **done)
         return out
 
-    s1 = run_stage("s1", 31, S1_MEAN, S1_STD, np.arange(n))
+    s1 = run_stage("s1", seeds[0], S1_MEAN, S1_STD, np.arange(n))
     p1 = torch.softmax(torch.from_numpy(s1), dim=1).numpy()            # forward_probs :111
     pred = np.where((p1.argmax(axis=1) == 1) & (p1[:, 1] >= 0.5), 1, 0)  # the gate, :312-320
-    idx = np.where(pred == 1)[0]
-    s2 = run_stage("s2", 33, S2_MEAN, S2_STD, idx)
+    # gate = False (weight sets whose stage-1 decisions do not vary with the input: the gate would pass all windows or none):
+    # stage 2 on every third window instead, compared forward by forward (no cascade call)
+    idx = np.where(pred == 1)[0] if gate else np.arange(0, n, 3)
+    s2 = run_stage("s2", seeds[1], S2_MEAN, S2_STD, idx)
     pool.close()
     margin = s1[:, 1] - s1[:, 0]
-    print(f"sens tail: {n} windows, {len(idx)} through the gate, stage-1 margin span {margin.min():.2f} .. {margin.max():.2f}")
-    np.savez_compressed(os.path.join(HERE, "sens_tail.npz"), s1_logits=s1, swallow_idx=idx.astype(np.int32), s2_logits=s2,
-                        rec_seed=rec_seed, n_windows=n, s1_seed=31, s2_seed=33, thr1=0.5,
+    print(f"{weight_set} tail: {n} windows, {len(idx)} through stage 2 ({'the gate' if gate else 'every third'}), stage-1 margin span "
+          f"{margin.min():.2f} .. {margin.max():.2f}")
+    np.savez_compressed(os.path.join(HERE, out_name), s1_logits=s1, swallow_idx=idx.astype(np.int32), s2_logits=s2,
+                        rec_seed=rec_seed, n_windows=n, s1_seed=seeds[0], s2_seed=seeds[1], thr1=0.5, gated=int(gate), weight_set=weight_set,
                         s1_mean=S1_MEAN, s1_std=S1_STD, s2_mean=S2_MEAN, s2_std=S2_STD)
 
 
 def main():
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
+    if "--heavy-tail" in sys.argv:      # adds heavy_tail.npz: the same recording size on the trained-like `heavy` set (another recording)
+        make_sens_tail(n=int(os.environ.get("SENS_TAIL_N", SENS_TAIL_N)), rec_seed=19, weight_set="heavy", seeds=(13, 14),
+                       out_name="heavy_tail.npz", gate=False)
+        return
     if "--sens-tail" in sys.argv:       # adds sens_tail.npz (about an hour) without touching the other fixtures
         make_sens_tail(n=int(os.environ.get("SENS_TAIL_N", SENS_TAIL_N)))     # other N: plumbing check, writes the same file name
         return
