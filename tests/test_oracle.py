@@ -96,16 +96,19 @@ def test_torch_cpu_baseline_pinned_on_the_input_sensitive_set(golden_dir):
     feats = tcpu.extract_features_parallel(list(synth.golden_windows()[:3]), float(fb["mean"]), float(fb["std"]), 3)
     logits = tcpu.TorchAST(synth.make_ast_weights(31, "sens")).forward(feats, chunk=3)
     assert np.abs(logits - g["sens_logits"][:3]).max() <= 1e-4
+    for name, wset in (("sens_tail.npz", "sens"), ("heavy_tail.npz", "heavy")):      # (heavy: the trained-like set, another recording)
+        t = np.load(os.path.join(golden_dir, name))
+        n = int(t["n_windows"])
+        rec = synth.synth_recording(int(t["rec_seed"]), 16000 + (n - 1) * 8000)
+        idx = t["swallow_idx"][[0, len(t["swallow_idx"]) // 2, -1]]      # windows for which both stages have a reference
+        wins = [rec[i * 8000: i * 8000 + 16000] for i in idx]
+        for st, (seed, ref) in enumerate(((int(t["s1_seed"]), t["s1_logits"][idx]),
+                                          (int(t["s2_seed"]), t["s2_logits"][np.searchsorted(t["swallow_idx"], idx)]))):
+            mean, std = float(t[f"s{st + 1}_mean"]), float(t[f"s{st + 1}_std"])
+            lg = tcpu.TorchAST(synth.make_ast_weights(seed, wset)).forward(tcpu.extract_features_parallel(wins, mean, std, 3), chunk=3)
+            assert np.abs(lg - ref).max() <= 1e-4, (name, st)
     t = np.load(os.path.join(golden_dir, "sens_tail.npz"))
     n = int(t["n_windows"])
-    rec = synth.synth_recording(int(t["rec_seed"]), 16000 + (n - 1) * 8000)
-    idx = t["swallow_idx"][[0, len(t["swallow_idx"]) // 2, -1]]      # gated windows: both stages have a reference
-    wins = [rec[i * 8000: i * 8000 + 16000] for i in idx]
-    for st, (seed, ref) in enumerate(((int(t["s1_seed"]), t["s1_logits"][idx]),
-                                      (int(t["s2_seed"]), t["s2_logits"][np.searchsorted(t["swallow_idx"], idx)]))):
-        mean, std = float(t[f"s{st + 1}_mean"]), float(t[f"s{st + 1}_std"])
-        lg = tcpu.TorchAST(synth.make_ast_weights(seed, "sens")).forward(tcpu.extract_features_parallel(wins, mean, std, 3), chunk=3)
-        assert np.abs(lg - ref).max() <= 1e-4, st
     # the fixture itself: the reference's gate (argmax == 1 and p >= thr1) applied to its own stage-1 logits
     p1 = orc.softmax(t["s1_logits"])
     assert np.array_equal(np.where((p1.argmax(1) == 1) & (p1[:, 1] >= float(t["thr1"])))[0], t["swallow_idx"])
