@@ -7,6 +7,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 bash tools/profile_round.sh "$TAG" > "gpurun_out/${TAG}_profile_round.log" 2>&1 || { tail -5 "gpurun_out/${TAG}_profile_round.log"; exit 1; }
 echo "profile round done"
+# (needs the stamp build: bash tools/build_variant.sh s2 "-DZK_C8_STAMPS=2")
 ZKP_TILED=1 CLOCK_JSON="gpurun_out/${TAG}_gemm_clock.json" python3 tools/gemm_stamps.py 512 s2 > "gpurun_out/${TAG}_gemm_clock.txt" 2>&1 || { tail -5 "gpurun_out/${TAG}_gemm_clock.txt"; exit 1; }
 echo "clock done"
 cp "gpurun_out/prof_${TAG}/pmc_traffic.json" "profiles/${TAG}_pmc_traffic.json"; cp "gpurun_out/${TAG}_gemm_clock.json" "profiles/${TAG}_gemm_clock.json"
